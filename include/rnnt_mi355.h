@@ -1,0 +1,134 @@
+/*
+ * rnnt_mi355.h — C ABI of librnnt_mi355.so, the MI355X (gfx950) RNN-Transducer loss.
+ *
+ * This is the drop-in boundary for the ONE native call the reference makes:
+ *     /root/reference/src/rnnt/model.py:5    from warprnnt_pytorch import RNNTLoss
+ *     /root/reference/src/rnnt/model.py:87   self.transducer_loss = RNNTLoss()
+ *     /root/reference/src/rnnt/model.py:116  self.transducer_loss(logits, tokens.int(), out_len, tok_len.int())
+ * warprnnt_pytorch (HawkAaron/warp-transducer, un-vendored, un-pinned:
+ * /root/reference/README.md:6,47) binds a native `get_workspace_size` +
+ * `compute_rnnt_loss` pair; the entry points below keep those two names and
+ * their argument meaning, and add the forward/backward split this library
+ * uses so that fwd+bwd costs exactly three passes over the logits.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types, no exceptions.
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed or torch-allocated);
+ *     the caller owns every buffer, including the workspace.  The library
+ *     allocates nothing, keeps no global state, never synchronises the host:
+ *     all work is enqueued on `options.stream`.
+ *   - acts   [B, maxT, maxU, V] contiguous raw (un-normalised) joint logits,
+ *            maxU = max label length + 1   (model.py:115 produces this layout)
+ *     labels [B, maxU-1] int32, zero padded, WITHOUT the BOS (model.py:116)
+ *     act_lens, label_lens [B] int32
+ *   - degenerate numerics give NaN/Inf in the costs, not an error status
+ *     (/root/reference/bin/train.py:36-41 consumes NaN/Inf losses).
+ */
+#ifndef RNNT_MI355_H_
+#define RNNT_MI355_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RNNT_STATUS_SUCCESS = 0,
+    RNNT_STATUS_MEMOPS_FAILED = 1,
+    RNNT_STATUS_INVALID_VALUE = 2,
+    RNNT_STATUS_EXECUTION_FAILED = 3,
+    RNNT_STATUS_UNKNOWN_ERROR = 4
+} rnntStatus_t;
+
+/* element type of acts and grads; the lattice (lse, alpha, beta, costs) is always fp32 */
+typedef enum { RNNT_DTYPE_F32 = 0, RNNT_DTYPE_BF16 = 1, RNNT_DTYPE_F16 = 2 } rnntDtype_t;
+
+typedef enum { RNNT_REDUCTION_NONE = 0, RNNT_REDUCTION_MEAN = 1, RNNT_REDUCTION_SUM = 2 } rnntReduction_t;
+
+typedef struct {
+    void *stream;     /* hipStream_t to enqueue on (NULL = the default stream)                     */
+    int blank_label;  /* upstream RNNTLoss(blank=0) default; the reference never overrides it      */
+    int maxT;         /* acts.shape[1]                                                             */
+    int maxU;         /* acts.shape[2] = max label length + 1                                      */
+    int dtype;        /* rnntDtype_t                                                               */
+    /* Optional stage timing: if non-NULL, hipEvent_t handles recorded on `stream` at the stage
+     * boundaries of rnnt_forward: [0] before K1, [1] after K1, [2] after K2 (+ cost reduction).
+     * rnnt_backward records [0] before and [1] after K3.  Used by bench.py; NULL in production. */
+    void *const *stage_events;
+} rnntOptions;
+
+/* Human-readable text for a status.  Mirrors upstream's rnntGetStatusString. */
+const char *rnntGetStatusString(rnntStatus_t status);
+
+/* Library/ABI version, bumped when a signature changes. */
+int rnnt_mi355_abi_version(void);
+
+/*
+ * Bytes of device workspace for a minibatch.  Replaces upstream's
+ * get_workspace_size(maxT, maxU, minibatch, gpu, &bytes) as bound by
+ * warprnnt_pytorch for the call at model.py:116.  The workspace holds the
+ * per-node denominators / blank / label log-probs written by K1, the alpha and
+ * beta lattices written by K2 and the per-utterance log-likelihoods; it must
+ * stay intact between rnnt_forward and rnnt_backward.  256-byte aligned.
+ */
+rnntStatus_t rnnt_get_workspace_size(int maxT, int maxU, int minibatch, size_t *size_bytes);
+/* upstream-compatible alias: gpu must be non-zero (this library has no CPU path) */
+rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, int gpu, size_t *size_bytes);
+
+/*
+ * Forward: K1 (log-softmax over V keeping lse / blank / next-label log-probs),
+ * K2 (alpha and beta over the T+U anti-diagonals, one workgroup per utterance)
+ * and the cost reduction.
+ *   costs    [B] fp32     <- -log P(y_b | x_b)      (always written)
+ *   loss_out fp32, may be NULL; [1] for MEAN (sum/B) / SUM, [B] for NONE
+ * Reads acts exactly once.  Replaces the forward half of the native call under
+ * RNNTLoss.forward (model.py:116).
+ */
+rnntStatus_t rnnt_forward(const void *acts, const int *labels, const int *act_lens,
+                          const int *label_lens, int alphabet_size, int minibatch, float *costs,
+                          float *loss_out, int reduction, void *workspace, rnntOptions options);
+
+/*
+ * Backward: K3, one fused pass that reads acts once more and writes every
+ * element of grads once (zeros in padded nodes):
+ *   grads[b] = grad_scale * grad_out[b * grad_out_stride] * d costs[b] / d acts[b]
+ * grad_out is a DEVICE pointer to the upstream gradient (stride 0 for a scalar
+ * loss, 1 for reduction NONE), so no host synchronisation is needed; NULL means 1.
+ * grad_scale carries 1/B for MEAN.  Replaces upstream's gradient computation
+ * plus the `grads * grad_output` / `grads / B` passes of its autograd glue
+ * (the loss.backward() at /root/reference/bin/train.py:43).
+ */
+rnntStatus_t rnnt_backward(const void *acts, void *grads, const int *labels, const int *act_lens,
+                           const int *label_lens, int alphabet_size, int minibatch,
+                           const float *grad_out, int grad_out_stride, float grad_scale,
+                           const void *workspace, rnntOptions options);
+
+/*
+ * Upstream-shaped single call: per-utterance costs and, when grads != NULL,
+ * unscaled d costs[b] / d acts[b] — what warprnnt_pytorch's binding obtains
+ * from the native library for the call at model.py:116.
+ */
+rnntStatus_t compute_rnnt_loss(const void *acts, void *grads, const int *labels,
+                               const int *label_lens, const int *act_lens, int alphabet_size,
+                               int minibatch, float *costs, void *workspace, rnntOptions options);
+
+/*
+ * The cost reduction on its own: loss_out = sum(costs)/B (MEAN), sum (SUM) or a copy (NONE), summed in
+ * index order so the result is bitwise reproducible.  Used by the batch-sharded harness
+ * (rnnt_amd/parallel.py) after its all-reduce of per-utterance costs, so that the sharded scalar equals
+ * the unsharded one bit for bit.  Counterpart of the `costs.sum() / B` in upstream's autograd glue.
+ */
+rnntStatus_t rnnt_reduce_costs(const float *costs, float *loss_out, int minibatch, int reduction,
+                               void *stream);
+
+/* hipEvent helpers so a ctypes caller (bench.py) can time stages without a HIP binding. */
+rnntStatus_t rnnt_event_create(void **event);
+rnntStatus_t rnnt_event_destroy(void *event);
+rnntStatus_t rnnt_event_record(void *event, void *stream);
+rnntStatus_t rnnt_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNT_MI355_H_ */

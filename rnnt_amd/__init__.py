@@ -1,0 +1,12 @@
+"""rnnt_amd — MI355X-native RNN-Transducer loss (drop-in for ``warprnnt_pytorch.RNNTLoss``).
+
+Scope: the one hot path the reference reaches at /root/reference/src/rnnt/model.py:116 plus the
+batch-sharding harness that replaces its ``DataParallel`` use (bin/train.py:241-244).
+See DESIGN.md.  Importing this package does not load the HIP library; the first loss call does,
+and raises if ``rnnt_amd/lib/librnnt_mi355.so`` is missing (no fallback exists).
+"""
+from .loss import RNNTLoss, rnnt_loss, certify_inputs  # noqa: F401
+from .parallel import ShardedRNNTLoss, shard_bounds, shard_batch  # noqa: F401
+
+__all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch"]
+__version__ = "0.1.0"

@@ -1,0 +1,136 @@
+"""Batch-sharded RNN-T loss: one process per GPU, one small collective.
+
+Replaces what the reference gets from ``torch.nn.DataParallel``
+(/root/reference/bin/train.py:241-244: one thread per GPU, batch scattered,
+per-replica losses gathered, ``loss / num_gpu`` at :34-35) for the loss path.
+The vendored ``src/parallel/parallel.py`` of the reference is dead code
+(nothing imports it) and is not reproduced.
+
+Utterances are independent, so each rank keeps its own slice of the logits and
+of the gradient; nothing of size N ever crosses xGMI.  The only exchange is the
+per-utterance cost vector (4·B bytes): every rank writes its costs into its
+slice of a zeroed ``[B_global]`` vector and one ``all_reduce(SUM)`` (RCCL on
+GPUs, gloo in the CPU tests) completes it.  Adding zeros is exact, so the
+result is bit-identical on every rank and to the unsharded cost vector; the
+scalar is then formed in a fixed summation order.  Backward needs no
+collective: each rank scales its local gradient by ``grad_out / B_global``
+inside K3.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard ``[lo, hi)`` of rank ``rank``; the first ``B % world`` ranks get one more."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    if global_batch < world_size:
+        raise ValueError("need at least one utterance per rank")
+    q, r = divmod(global_batch, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_batch(acts, labels, act_lens, label_lens, world_size: int, rank: int):
+    """Slice a (padded) global batch for one rank.  Views along dim 0 stay contiguous.
+
+    T and U are NOT re-trimmed to the shard's own maxima: the loss accepts
+    ``T >= max(act_lens)`` / ``U+1 >= max(label_lens)+1``, which is exactly the
+    situation the reference's DataParallel scatter creates.
+    """
+    lo, hi = shard_bounds(acts.shape[0], world_size, rank)
+    return acts[lo:hi], labels[lo:hi], act_lens[lo:hi], label_lens[lo:hi]
+
+
+def _default_loss_fn(acts, labels, act_lens, label_lens, blank):
+    from .loss import rnnt_loss
+
+    return rnnt_loss(acts, labels, act_lens, label_lens, blank=blank, reduction="none")
+
+
+def ordered_reduce(costs: torch.Tensor, reduction: str) -> torch.Tensor:
+    """``[1]``: sum (or sum / B) of a small fp32 vector in index order — the order ``rnnt_forward``
+    uses — so every rank and the unsharded run obtain the same bits.
+
+    Device tensors use the library's reduction kernel (no host sync).  Host tensors (the gloo
+    tests, which inject a CPU ``loss_fn``) are summed by a plain fp32 loop.
+    """
+    if costs.is_cuda:
+        from .loss import reduce_costs
+
+        return reduce_costs(costs.detach().contiguous(), reduction)
+    c = costs.detach().to(torch.float32)
+    s = torch.zeros((), dtype=torch.float32)
+    for i in range(c.numel()):
+        s = s + c[i]
+    if reduction == "mean":
+        s = s / torch.tensor(float(c.numel()), dtype=torch.float32)
+    return s.reshape(1)
+
+
+class ShardedRNNTLoss(torch.nn.Module):
+    """RNN-T loss over a batch that is sharded across the ranks of a process group.
+
+    Each rank calls it with ITS shard; every rank receives the loss of the whole batch
+    (``'mean'`` divides by the global batch size) and, on ``backward()``, the gradient of that
+    global loss w.r.t. its local logits.
+
+    Args:
+        blank, reduction: as :class:`rnnt_amd.RNNTLoss`.
+        group: process group (default: the world).
+        loss_fn: ``f(acts, labels, act_lens, label_lens, blank) -> [B_local] costs`` with autograd.
+            Defaults to the HIP kernels.  The CPU (gloo) tests inject the oracle here; the
+            product default never touches a CPU implementation.
+    """
+
+    def __init__(self, blank: int = 0, reduction: str = "mean", group=None,
+                 loss_fn: Optional[Callable] = None):
+        super().__init__()
+        if reduction not in ("none", "mean", "sum"):
+            raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
+        self.blank = blank
+        self.reduction = reduction
+        self.group = group
+        self.loss_fn = loss_fn or _default_loss_fn
+
+    def forward(self, acts, labels, act_lens, label_lens, global_batch: Optional[int] = None,
+                offset: Optional[int] = None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("ShardedRNNTLoss needs an initialised torch.distributed process group")
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        b_local = acts.shape[0]
+        if global_batch is None:
+            global_batch = b_local * world  # equal shards
+        if offset is None:
+            lo, hi = shard_bounds(global_batch, world, rank)
+            if hi - lo != b_local:
+                raise ValueError(
+                    f"rank {rank} holds {b_local} utterances but shard_bounds gives {hi - lo}; "
+                    "pass offset= for a custom partition")
+            offset = lo
+        if offset < 0 or offset + b_local > global_batch:
+            raise ValueError("shard does not fit the global batch")
+
+        local = self.loss_fn(acts, labels, act_lens, label_lens, self.blank)  # [B_local], autograd
+        if local.shape != (b_local,):
+            raise RuntimeError("loss_fn must return one cost per local utterance")
+
+        # the one collective: per-utterance costs, 4*B_global bytes, latency-bound
+        gathered = torch.zeros(global_batch, dtype=torch.float32, device=local.device)
+        gathered[offset:offset + b_local] = local.detach()
+        dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group)
+
+        if self.reduction == "none":
+            out = gathered.clone()
+            out[offset:offset + b_local] = local  # local slice carries the graph
+            return out
+        factor = 1.0 / global_batch if self.reduction == "mean" else 1.0
+        value = ordered_reduce(gathered, self.reduction)
+        # value of the global loss, gradient only through this rank's utterances
+        local_sum = local.sum()
+        return value + (local_sum - local_sum.detach()) * factor
