@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — RNN-T loss fwd+bwd throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config5|config1]
+
+One "step" = RNNTLoss forward + backward over one synthetic batch already resident in HBM.
+N=1 runs BASELINE.json configs[1] (B=32, T=400, U=40, V=4232, fp32).  For N>1 the driver starts
+one rank per GPU with torch.distributed.run; every rank owns B=32 utterances (weak scaling, so
+N=8 is configs[3], B=256) and the ranks exchange only the per-utterance costs (one RCCL
+all-reduce of 4·B bytes, rnnt_amd/parallel.py).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (K3, the fused gradient
+pass): algorithmic bytes per launch (read N_valid + write N_full elements) over its mean
+duration measured with hipEvents that the library records on the launch stream.  `cpu_baseline`
+is the CPU oracle (oracle/rnnt_oracle.c, a restatement of warp-transducer's CPU semantics — NOT
+warp-transducer itself) timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+WORKLOADS = {
+    # name: (B per GPU, T, U, V, dtype, ragged)
+    "config1": dict(B=8, T=200, U=20, V=4232, dtype="f32", ragged=False),
+    "config2": dict(B=32, T=400, U=40, V=4232, dtype="f32", ragged=False),
+    "config3": dict(B=64, T=800, U=60, V=4232, dtype="f32", ragged=True),
+    "config5": dict(B=16, T=1500, U=150, V=16384, dtype="bf16", ragged=False),
+}
+TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def make_device_batch(w, dev, first_utt, seed=1234):
+    """Per-utterance seeded N(0,1) logits generated on the device (shard-invariant)."""
+    B, T, U, V = w["B"], w["T"], w["U"], w["V"]
+    dt = TORCH_DTYPES[w["dtype"]]
+    acts = torch.empty((B, T, U + 1, V), dtype=dt, device=dev)
+    g = torch.Generator(device=dev)
+    for b in range(B):
+        g.manual_seed(seed + first_utt + b)
+        if dt is torch.float32:
+            acts[b].normal_(0.0, 1.0, generator=g)
+        else:
+            for t0 in range(0, T, 100):  # bounded fp32 temporaries
+                t1 = min(T, t0 + 100)
+                acts[b, t0:t1] = torch.randn((t1 - t0, U + 1, V), device=dev, generator=g).to(dt)
+    rng = np.random.default_rng(4321 + first_utt)
+    labels = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    if w["ragged"]:
+        act_lens = rng.integers(100, T + 1, size=B).astype(np.int32)
+        label_lens = rng.integers(10, U + 1, size=B).astype(np.int32)
+        act_lens[0], label_lens[0] = T, U
+        for b in range(B):
+            labels[b, label_lens[b]:] = 0
+    else:
+        act_lens = np.full(B, T, np.int32)
+        label_lens = np.full(B, U, np.int32)
+    return (acts, torch.from_numpy(labels).to(dev), torch.from_numpy(act_lens).to(dev),
+            torch.from_numpy(label_lens).to(dev), act_lens, label_lens)
+
+
+def cpu_baseline(w, sample_B, reps):
+    """CPU oracle (restatement of warp-transducer's CPU path) on a bounded sample, host cores."""
+    import oracle  # test infrastructure: used here only as the reported CPU baseline
+
+    oracle.build()
+    B, T, U, V = sample_B, w["T"], w["U"], w["V"]
+    g = torch.Generator().manual_seed(1234)
+    acts = torch.empty((B, T, U + 1, V), dtype=torch.float32).normal_(0, 1, generator=g).numpy()
+    rng = np.random.default_rng(4321)
+    labels = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    al = np.full(B, T, np.int32)
+    ll = np.full(B, U, np.int32)
+    threads = oracle.max_threads()
+    oracle.rnnt_loss_c(acts[:1], labels[:1], al[:1], ll[:1])  # warm-up (page in, thread pool)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        c, gr, _ = oracle.rnnt_loss_c(acts, labels, al, ll, want_grads=True)
+        oracle.reduce_like_upstream(c, None, "mean")
+        ts.append(time.perf_counter() - t0)
+        del gr
+    t = float(np.median(ts))
+    return {
+        "value": B / t, "unit": "utt/s", "cores": int(min(threads, B)), "kind": "port",
+        "sample": f"CPU restatement of warp-transducer semantics (oracle/rnnt_oracle.c, OpenMP, one "
+                  f"utterance per thread), fwd+bwd on B={B} utterances of T={T} U={U} V={V} fp32, "
+                  f"median of {reps} runs, {t * 1e3:.0f} ms per run; omp_max_threads={threads}, "
+                  f"os.cpu_count={os.cpu_count()}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-b", type=int, default=16)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--no-check-lengths", action="store_true",
+                    help="skip the host-side length check (fully asynchronous forward)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch.distributed as dist
+
+    import rnnt_amd
+    from rnnt_amd import _lib, loss as loss_mod
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; rnnt_amd has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    w = dict(WORKLOADS[args.workload])
+    B = w["B"]
+    acts, labels, al_d, ll_d, al, ll = make_device_batch(w, dev, first_utt=rank * B)
+    acts.requires_grad_(True)
+    go = torch.full((1,), 0.5, dtype=torch.float32, device=dev)  # grad_output != 1 exercises the fused scale
+
+    if world > 1:
+        crit = rnnt_amd.ShardedRNNTLoss(blank=0, reduction="mean")
+
+        def step():
+            acts.grad = None
+            loss = crit(acts, labels, al_d, ll_d, global_batch=B * world)
+            loss.backward(go)
+            return loss
+    else:
+        crit = rnnt_amd.RNNTLoss(blank=0, reduction="mean", check_lengths=not args.no_check_lengths)
+
+        def step():
+            acts.grad = None
+            loss = crit(acts, labels, al_d, ll_d)
+            loss.backward(go)
+            return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+
+    fwd_ev = [_lib.StageEvents(3) for _ in range(args.steps)]
+    bwd_ev = [_lib.StageEvents(2) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_mod.set_stage_events(fwd_ev[i], bwd_ev[i])
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    loss_mod.set_stage_events(None, None)
+
+    k1 = float(np.mean([e.elapsed_ms(0, 1) for e in fwd_ev]))
+    k2 = float(np.mean([e.elapsed_ms(1, 2) for e in fwd_ev]))
+    k3 = float(np.mean([e.elapsed_ms(0, 1) for e in bwd_ev]))
+    loss_val = float(loss.detach().cpu()[0])
+
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    elapsed = float(t_all.item())
+
+    esz = 4 if w["dtype"] == "f32" else 2
+    V = w["V"]
+    n_valid = int(sum(int(t) * (int(u) + 1) for t, u in zip(al, ll))) * V
+    n_full = B * w["T"] * (w["U"] + 1) * V
+    k3_bytes = (n_valid + n_full) * esz           # K3: read valid logits once, write every grad once
+    k1_bytes = n_valid * esz                      # K1: read valid logits once
+    step_bytes = (2 * n_valid + n_full) * esz     # SURVEY.md §8d algorithmic bytes per batch
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world / (elapsed / args.steps)
+
+    out = {
+        "metric": "RNNT loss fwd+bwd utts/sec at B32 T400 U40 V4232; % of HBM BW roofline",
+        "value": round(value, 2),
+        "unit": "utt/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": w["dtype"],
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: RNN-T loss fwd+bwd, B={B} per GPU x {world} GPU(s), T={w['T']}, "
+                        f"U={w['U']}, V={V}, {w['dtype']} logits+grads, fp32 lattice, "
+                        f"{'ragged' if w['ragged'] else 'uniform'} lengths, N(0,1) logits, grad_output=0.5, "
+                        f"reduction=mean",
+            "global_batch": B * world,
+            "parallelism": f"batch-sharded x{world}, all-reduce of per-utterance costs" if world > 1 else "single GPU",
+            "check_lengths": not args.no_check_lengths,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "rnnt_k3_grad (fused gradient: read logits, write grads)",
+            "achieved": round(k3_bytes / (k3 * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(k3_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": k3_bytes,
+            "avg_launch_ms": round(k3, 4),
+        },
+        "stages_ms": {"k1_lse": round(k1, 4), "k2_lattice_and_reduce": round(k2, 4), "k3_grad": round(k3, 4)},
+        "k1_achieved_GBs": round(k1_bytes / (k1 * 1e-3) / 1e9, 1),
+        "whole_step": {
+            "algorithmic_bytes": step_bytes,
+            "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        },
+        "loss": loss_val,
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "k3_traffic.json")
+    if os.path.exists(traffic_file) and args.workload == "config2":
+        try:
+            with open(traffic_file) as f:
+                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # free the device tensors' host shadows first; the CPU sample needs a few GB of RAM
+        out["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.cpu_sample_b, args.cpu_reps)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

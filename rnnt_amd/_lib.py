@@ -12,7 +12,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librnnt_mi355.so")
+# RNNT_AMD_LIB: developer override to A/B differently-built libraries (tools/sweep.sh)
+LIB_PATH = os.environ.get("RNNT_AMD_LIB") or os.path.join(_HERE, "lib", "librnnt_mi355.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 ABI_VERSION = 1
 

@@ -20,6 +20,7 @@
 // so that one anti-diagonal is contiguous and K2's loads/stores are coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/rnnt_mi355.h"
 
@@ -145,51 +146,82 @@ __device__ __forceinline__ RowCoord decode_row(long long r, int maxT, int U1) {
 __device__ __forceinline__ bool lens_ok(int Tb, int Ub, int maxT, int U1) {
     return Tb >= 1 && Tb <= maxT && Ub >= 0 && Ub < U1;
 }
-__device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int U1) {
-    return ((size_t)b * ND + (size_t)(t + u)) * U1 + u;
+// Skewed lattice layout: one anti-diagonal d = t+u of one utterance is one row of US floats
+// (US = U1 rounded up to a multiple of 64, so a wave reads/writes whole aligned 256-byte rows).
+__device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US) {
+    return ((size_t)b * (ND + 1) + (size_t)(t + u)) * US + u;  // +1: K2's junk row
 }
+
+struct Lattice {      // device pointers into the workspace
+    float *lse;       // log sum_v exp(x_v) per node
+    float2 *lp;       // {lp_blank, lp_label} per node
+    float *alpha;
+    float *beta;
+    float *ll;        // [B] forward log-likelihood
+    int ND;           // anti-diagonals per utterance = maxT + maxU - 1
+    int US;           // row stride of the skewed layout
+};
 
 // ---------------------------------------------------------------------------------------------
 // K1: log-softmax denominators; keep blank and next-label log-probs.  
-// Bound: HBM read of N_valid elements.  One wave per node, NCH 16-byte chunks per lane.
+// Bound: HBM read of N_valid elements.  WPR waves per node (1 for V*elem <= 17 KiB), each wave
+// holds NCH 16-byte chunks per lane in registers; max and sum-exp are reduced with wave
+// butterflies and, for WPR > 1, a two-word LDS exchange.
 // ---------------------------------------------------------------------------------------------
-template <typename DT, int NCH>
-__global__ __launch_bounds__(256) void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
+// Waves per SIMD that stream fastest, by bytes a wave keeps in flight (NCH KiB).  Measured on
+// config 2 (NCH = 17): K1 reads 6.91 TB/s at 3 waves/SIMD against 6.76 at 4 and 6.1 at 2; K3 runs
+// 3.07 ms at 2 waves/SIMD (one 512-thread workgroup per CU) against 3.17 at 4.  Fewer, larger
+// bursts per CU suit HBM better than maximum occupancy; smaller rows get more waves to keep
+// roughly the same bytes in flight per CU.
+constexpr int k1_waves(int nch) { return nch >= 16 ? 3 : nch >= 12 ? 4 : nch >= 8 ? 6 : 8; }
+constexpr int k3_waves(int nch) { return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 6 : 8; }
+
+template <typename DT, int NCH, int WPR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH), k1_waves(NCH))))
+void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ labels,
                                                    const int *__restrict__ act_lens,
-                                                   const int *__restrict__ label_lens,
-                                                   float *__restrict__ lse, float *__restrict__ lpB,
-                                                   float *__restrict__ lpY, int maxT, int U1, int V,
-                                                   int blank, int ND, long long total_rows) {
+                                                   const int *__restrict__ label_lens, Lattice L,
+                                                   int maxT, int U1, int V, int blank,
+                                                   long long total_rows) {
     constexpr int EPC = DT::EPC;
+    constexpr int WPB = 4;          // waves per workgroup (host launches 256 threads)
+    constexpr int RPB = WPB / WPR;  // nodes per workgroup
+    __shared__ float red[2][WPB];
     const int lane = threadIdx.x & (kWave - 1);
-    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and nchunks <= NCH*64
+    const int wave = threadIdx.x / kWave;
+    const int rib = wave / WPR;
+    const int seg = wave - rib * WPR;
+    const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and nchunks <= WPR*NCH*64
+    const long long ngroups = (total_rows + RPB - 1) / RPB;
 
-    for (long long r = wave0; r < total_rows; r += nwaves) {
-        const RowCoord c = decode_row(r, maxT, U1);
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {  // host launches ngroups blocks
+        const long long r = g * RPB + rib;
+        bool valid = r < total_rows;
+        const RowCoord c = decode_row(valid ? r : 0, maxT, U1);
         const int Tb = act_lens[c.b];
         const int Ub = label_lens[c.b];
-        if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) continue;  // padded node: never read
+        valid = valid && lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub;  // padded node: never read
+        if (WPR == 1 && !valid) continue;
 
-        const typename DT::elem *row = acts + (size_t)r * (size_t)V;
+        const typename DT::elem *row = acts + (size_t)(valid ? r : 0) * (size_t)V;
         const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
+        const int c0 = seg * NCH * kWave + lane;
         u32x4 raw[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int idx = lane + k * kWave;
-            if (idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
+            const int idx = c0 + k * kWave;
+            if (valid && idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
         }
         // blank / label logits: tiny extra loads that hit the lines fetched above
-        const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
+        const int y = (valid && c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
         const float xb = DT::to_float(row[blank]);
         const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
 
         float m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (lane + k * kWave < nchunks) {
+            if (valid && c0 + k * kWave < nchunks) {
                 float x[EPC];
                 DT::unpack(raw[k], x);
 #pragma unroll
@@ -197,12 +229,26 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse(const typename DT::elem *__re
             }
         }
         m = wave_max(m);
+        if (EPC > 4) {
+            // 16-bit logits: make `raw` opaque here so the second pass re-unpacks it (two shifts)
+            // instead of keeping 8 floats per chunk alive across the reduction (2x the registers).
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));
+        }
+        if (WPR > 1) {
+            red[0][wave] = m;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < WPR; ++i) m = fmaxf(m, red[0][rib * WPR + i]);
+        }
         // all -inf row (or +inf max): avoid inf-inf; the result is NaN/-inf downstream as in torch
-        const float mneg = (m == -INFINITY || m == INFINITY) ? 0.0f : -m * kLog2e;
+        const float mm = (m == -INFINITY || m == INFINITY) ? 0.0f : m;
+        const float mneg = -mm * kLog2e;
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (lane + k * kWave < nchunks) {
+            if (valid && c0 + k * kWave < nchunks) {
                 float x[EPC];
                 DT::unpack(raw[k], x);
 #pragma unroll
@@ -210,14 +256,19 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse(const typename DT::elem *__re
             }
         }
         s = wave_sum(s);
-        if (lane == 0) {
+        if (WPR > 1) {
+            red[1][wave] = s;
+            __syncthreads();
+            s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < WPR; ++i) s += red[1][rib * WPR + i];  // fixed order: reproducible
+        }
+        if (valid && seg == 0 && lane == 0) {
             const float logs = __logf(s);
-            const size_t o = skew_index(c.b, c.t, c.u, ND, U1);
-            const float mm = (m == -INFINITY || m == INFINITY) ? 0.0f : m;
-            lse[o] = mm + logs;
+            const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+            L.lse[o] = mm + logs;
             // same association as torch.log_softmax on the upstream CPU path: (x - max) - log(sum)
-            lpB[o] = (xb - mm) - logs;
-            lpY[o] = (xy - mm) - logs;
+            L.lp[o] = make_float2((xb - mm) - logs, (xy - mm) - logs);
         }
     }
 }
@@ -226,9 +277,8 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse(const typename DT::elem *__re
 template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
     const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
-    const int *__restrict__ act_lens, const int *__restrict__ label_lens, float *__restrict__ lse,
-    float *__restrict__ lpB, float *__restrict__ lpY, int maxT, int U1, int V, int blank, int ND,
-    long long total_rows) {
+    const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
+    int V, int blank, long long total_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
@@ -249,10 +299,10 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
         if (lane == 0) {
             const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
             const float logs = __logf(s);
-            const size_t o = skew_index(c.b, c.t, c.u, ND, U1);
-            lse[o] = mm + logs;
-            lpB[o] = (DT::to_float(row[blank]) - mm) - logs;
-            lpY[o] = (((y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("")) - mm) - logs;
+            const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+            const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
+            L.lse[o] = mm + logs;
+            L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (xy - mm) - logs);
         }
     }
 }
@@ -260,6 +310,9 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
 // ---------------------------------------------------------------------------------------------
 // K2: alpha / beta over anti-diagonals.  
 // Latency-bound: T+U dependent steps.  Block = 2*NW waves; waves [0,NW) alpha, [NW,2NW) beta.
+// The inner loop is branch-free: every lane loads and stores a (possibly unused) slot of its
+// utterance's skewed plane each step, and invalid lanes carry -inf, so the compiler can keep
+// kPF diagonals of {lp_blank, lp_label} in flight behind counted s_waitcnt vmcnt(N).
 // ---------------------------------------------------------------------------------------------
 // DPP whole-wave shifts by one lane (GFX9 dpp_ctrl wave_shr:1 = 0x138, wave_shl:1 = 0x130).
 // Lanes with no source keep `fill`.
@@ -272,22 +325,24 @@ __device__ __forceinline__ float wave_shift_down(float v, float fill) {  // lane
                                                        0x130, 0xf, 0xf, false));
 }
 
-// log(e^a + e^b), same arrangement as the upstream CPU helper: big + log1p(exp(small - big)).
+// log(e^a + e^b) = big + log(1 + e^(small-big)), the arrangement of the upstream CPU helper.
+// Branch-free: a -inf operand gives exactly the other one; -inf with -inf gives -inf (the fminf
+// drops the NaN of inf-inf).  v_exp_f32 / v_log_f32 directly: the argument of the log is in [1,2].
 __device__ __forceinline__ float log_add_exp(float a, float b) {
     const float big = fmaxf(a, b);
-    const float small = fminf(a, b);
-    if (small == -INFINITY) return big;
-    return big + log1pf(__expf(small - big));
+    const float d = fminf(fminf(a, b) - big, 0.0f);
+    return big + kLn2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(d * kLog2e));
 }
 
-constexpr int kPF = 16;  // diagonals of lp_blank/lp_label kept in flight per lane
+constexpr int kPF = 16;  // diagonals per register set; two sets ping-pong, so 16..32 rows are in flight
 
 template <int NW>
-__global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(
-    const float *__restrict__ lpB, const float *__restrict__ lpY, float *__restrict__ alpha,
-    float *__restrict__ beta, float *__restrict__ ll, float *__restrict__ costs,
-    const int *__restrict__ act_lens, const int *__restrict__ label_lens, int U1, int ND) {
-    __shared__ float xch[2][2][NW > 1 ? NW : 1];  // [direction][step parity][wave]: edge lanes
+__global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(Lattice L, float *__restrict__ costs,
+                                                                  const int *__restrict__ act_lens,
+                                                                  const int *__restrict__ label_lens,
+                                                                  int maxT, int U1) {
+    constexpr int US = NW * kWave;
+    __shared__ float xch[2][2][NW];  // [direction][step parity][wave]: values crossing a wave edge
     const int b = blockIdx.x;
     const int T = act_lens[b];
     const int U = label_lens[b];  // labels; lattice columns 0..U
@@ -296,122 +351,121 @@ __global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(
     const int dir = wave / NW;
     const int w = wave - dir * NW;
     const int u = w * kWave + lane;
-    if (!lens_ok(T, U, ND - U1 + 1, U1)) {  // block-uniform exit, before any barrier
+    if (!lens_ok(T, U, maxT, U1)) {  // block-uniform exit, before any barrier
         if (threadIdx.x == 0) {
-            ll[b] = __builtin_nanf("");
+            L.ll[b] = __builtin_nanf("");
             costs[b] = __builtin_nanf("");
         }
         return;
     }
-    const int nd = T + U;  // diagonals 0 .. nd-1
-    const size_t base = (size_t)b * ND * U1;
+    const int nd = T + U;                                     // diagonals 0 .. nd-1
+    const int nsteps = (nd + 2 * kPF - 1) / (2 * kPF) * (2 * kPF);  // whole groups; surplus steps
+    const int junk = L.ND;                                    // store into the utterance's junk row
+    const size_t base = (size_t)b * (L.ND + 1) * US;
+    const float2 *__restrict__ lp = L.lp + base + u;
     const bool col_ok = (u <= U);
+    const float NEG = -INFINITY;
 
     if (dir == 0) {
-        // ---- alpha: diagonal d needs row d-1 of lpB (column u) and lpY (column u-1)
-        float pb[kPF], py[kPF];
+        // ---- alpha: step d consumes row d-1: lp_blank(t-1,u) from column u, lp_label(t,u-1) from column u-1
+        float *__restrict__ out = L.alpha + base + u;
+        const float2 *__restrict__ lpl = lp - (u > 0 ? 1 : 0);  // column u-1 (NW > 1 only)
+        float a_prev = NEG, a_last = NEG;
+        auto row_of = [&](int d) { return (size_t)min(max(d - 1, 0), nd - 1) * US; };
+        auto step = [&](int d, const float2 cur, float lpy_left) {
+            if (NW == 1) lpy_left = wave_shift_up(cur.y, 0.0f);
+            float left = wave_shift_up(a_prev, NEG);
+            if (NW > 1) {
+                const float edge = xch[0][(d + 1) & 1][w > 0 ? w - 1 : 0];  // written at step d-1
+                left = (lane == 0 && w > 0) ? edge : left;
+            }
+            const int t = d - u;
+            const float up_term = (t > 0) ? a_prev + cur.x : NEG;
+            const float left_term = (u > 0 && d > 0) ? left + lpy_left : NEG;
+            float a = log_add_exp(left_term, up_term);
+            a = (d == 0 && u == 0) ? 0.0f : a;
+            a = (col_ok && t >= 0 && t < T) ? a : NEG;
+            out[(size_t)(d < nd ? d : junk) * US] = a;
+            a_prev = a;
+            a_last = (d == nd - 1) ? a : a_last;
+            if (NW > 1) {
+                if (lane == kWave - 1) xch[0][d & 1][w] = a;
+                __syncthreads();
+            }
+        };
+        float2 ra[kPF], rb[kPF];
+        float la[NW > 1 ? kPF : 1], lb[NW > 1 ? kPF : 1];
 #pragma unroll
         for (int i = 0; i < kPF; ++i) {
-            const int dd = i - 1;  // row read at step i
-            const bool ok = col_ok && dd >= 0 && dd < nd;
-            pb[i] = ok ? lpB[base + (size_t)dd * U1 + u] : 0.0f;
-            py[i] = (ok && u > 0) ? lpY[base + (size_t)dd * U1 + u - 1] : 0.0f;
+            ra[i] = lp[row_of(i)];
+            if (NW > 1) la[i] = lpl[row_of(i)].y;
         }
-        float a_prev = -INFINITY;
-        for (int d0 = 0; d0 < nd; d0 += kPF) {
+        for (int d0 = 0; d0 < nsteps; d0 += 2 * kPF) {
 #pragma unroll
-            for (int i = 0; i < kPF; ++i) {
-                const int d = d0 + i;
-                const float cb = pb[i], cy = py[i];
-                {  // refill this ring slot for step d + kPF
-                    const int dd = d + kPF - 1;
-                    const bool ok = col_ok && dd < nd;
-                    pb[i] = ok ? lpB[base + (size_t)dd * U1 + u] : 0.0f;
-                    py[i] = (ok && u > 0) ? lpY[base + (size_t)dd * U1 + u - 1] : 0.0f;
-                }
-                if (d < nd) {  // block-uniform
-                    float left = wave_shift_up(a_prev, -INFINITY);
-                    if (NW > 1) {
-                        if (lane == 0 && w > 0 && d > 0) left = xch[0][(d - 1) & 1][w - 1];
-                    }
-                    const int t = d - u;
-                    const bool active = col_ok && t >= 0 && t < T;
-                    const float up_term = a_prev + cb;
-                    const float left_term = left + cy;
-                    float a;
-                    if (t == 0)
-                        a = (u == 0) ? 0.0f : left_term;
-                    else
-                        a = (u == 0) ? up_term : log_add_exp(left_term, up_term);
-                    a = active ? a : -INFINITY;
-                    if (active) alpha[base + (size_t)d * U1 + u] = a;
-                    a_prev = a;
-                    if (NW > 1) {
-                        if (lane == kWave - 1) xch[0][d & 1][w] = a;
-                        __syncthreads();
-                    }
-                }
+            for (int i = 0; i < kPF; ++i) {  // consume set A, refill set B for steps d0+kPF ..
+                rb[i] = lp[row_of(d0 + kPF + i)];
+                if (NW > 1) lb[i] = lpl[row_of(d0 + kPF + i)].y;
+                step(d0 + i, ra[i], NW > 1 ? la[i] : 0.0f);
+            }
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {  // consume set B, refill set A for steps d0+2*kPF ..
+                ra[i] = lp[row_of(d0 + 2 * kPF + i)];
+                if (NW > 1) la[i] = lpl[row_of(d0 + 2 * kPF + i)].y;
+                step(d0 + kPF + i, rb[i], NW > 1 ? lb[i] : 0.0f);
             }
         }
         // the last diagonal holds alpha(T-1,U) in lane u == U
         if (u == U) {
-            const float v = a_prev + lpB[base + (size_t)(nd - 1) * U1 + U];
-            ll[b] = v;
+            const float v = a_last + lp[(size_t)(nd - 1) * US].x;
+            L.ll[b] = v;
             costs[b] = -v;
         }
     } else {
-        // ---- beta: diagonal d (descending) needs row d of lpB and lpY (column u)
-        float pb[kPF], py[kPF];
+        // ---- beta: step s handles diagonal d = nd-1-s and consumes row d, column u
+        float *__restrict__ out = L.beta + base + u;
+        float b_prev = NEG;
+        auto row_of = [&](int s) { return (size_t)max(nd - 1 - s, 0) * US; };
+        auto step = [&](int s, const float2 cur) {
+            const int d = nd - 1 - s;
+            float right = wave_shift_down(b_prev, NEG);
+            if (NW > 1) {
+                const float edge = xch[1][(s + 1) & 1][w < NW - 1 ? w + 1 : 0];  // written at step s-1
+                right = (lane == kWave - 1 && w < NW - 1 && s > 0) ? edge : right;
+            }
+            const int t = d - u;
+            const float down_term = (t < T - 1) ? b_prev + cur.x : NEG;  // beta(t+1,u) + lp_blank(t,u)
+            const float right_term = (u < U) ? right + cur.y : NEG;      // beta(t,u+1) + lp_label(t,u)
+            float v = log_add_exp(right_term, down_term);
+            v = (t == T - 1 && u == U) ? cur.x : v;
+            v = (col_ok && t >= 0 && t < T) ? v : NEG;
+            out[(size_t)(d >= 0 ? d : junk) * US] = v;
+            b_prev = v;
+            if (NW > 1) {
+                if (lane == 0) xch[1][s & 1][w] = v;
+                __syncthreads();
+            }
+        };
+        float2 ra[kPF], rb[kPF];
 #pragma unroll
-        for (int i = 0; i < kPF; ++i) {
-            const int dd = nd - 1 - i;
-            const bool ok = col_ok && dd >= 0;
-            pb[i] = ok ? lpB[base + (size_t)dd * U1 + u] : 0.0f;
-            py[i] = ok ? lpY[base + (size_t)dd * U1 + u] : 0.0f;
-        }
-        float b_prev = -INFINITY;
-        for (int s0 = 0; s0 < nd; s0 += kPF) {
+        for (int i = 0; i < kPF; ++i) ra[i] = lp[row_of(i)];
+        for (int s0 = 0; s0 < nsteps; s0 += 2 * kPF) {
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {
-                const int s = s0 + i;
-                const int d = nd - 1 - s;
-                const float cb = pb[i], cy = py[i];
-                {
-                    const int dd = d - kPF;
-                    const bool ok = col_ok && dd >= 0;
-                    pb[i] = ok ? lpB[base + (size_t)dd * U1 + u] : 0.0f;
-                    py[i] = ok ? lpY[base + (size_t)dd * U1 + u] : 0.0f;
-                }
-                if (s < nd) {
-                    float right = wave_shift_down(b_prev, -INFINITY);
-                    if (NW > 1) {
-                        if (lane == kWave - 1 && w < NW - 1 && s > 0) right = xch[1][(s - 1) & 1][w + 1];
-                    }
-                    const int t = d - u;
-                    const bool active = col_ok && t >= 0 && t < T;
-                    const float down_term = b_prev + cb;   // beta(t+1,u) + lp_blank(t,u)
-                    const float right_term = right + cy;   // beta(t,u+1) + lp_label(t,u)
-                    float v;
-                    if (t == T - 1)
-                        v = (u == U) ? cb : right_term;
-                    else
-                        v = (u == U) ? down_term : log_add_exp(right_term, down_term);
-                    v = active ? v : -INFINITY;
-                    if (active) beta[base + (size_t)d * U1 + u] = v;
-                    b_prev = v;
-                    if (NW > 1) {
-                        if (lane == 0) xch[1][s & 1][w] = v;
-                        __syncthreads();
-                    }
-                }
+                rb[i] = lp[row_of(s0 + kPF + i)];
+                step(s0 + i, ra[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                ra[i] = lp[row_of(s0 + 2 * kPF + i)];
+                step(s0 + kPF + i, rb[i]);
             }
         }
     }
 }
 
 // costs -> loss_out, fixed summation order (bitwise reproducible, identical on every rank)
-__global__ void rnnt_reduce_costs_kernel(const float *__restrict__ costs, float *__restrict__ loss_out, int B,
-                                  int reduction) {
+__global__ void rnnt_reduce_costs_kernel(const float *__restrict__ costs, float *__restrict__ loss_out,
+                                         int B, int reduction) {
     if (reduction == RNNT_REDUCTION_NONE) {
         for (int i = threadIdx.x; i < B; i += blockDim.x) loss_out[i] = costs[i];
         return;
@@ -426,23 +480,92 @@ __global__ void rnnt_reduce_costs_kernel(const float *__restrict__ costs, float 
 // ---------------------------------------------------------------------------------------------
 // K3: fused gradient.  (SURVEY.md §8a A5 + A6)
 // Bound: HBM read N_valid + write N_full.  One wave per node.
-//   g_v = scale * ( softmax_v * e^{alpha+beta-ll}  - [v=blank] Bk - [v=y_u] Yk )
+//   g_v = scale * ( softmax_v * (Bk + Yk)  - [v=blank] Bk - [v=y_u] Yk )
 // ---------------------------------------------------------------------------------------------
-template <typename DT, int NCH>
-__global__ __launch_bounds__(256) void rnnt_k3_grad(
+struct NodeCoef {
+    float sa;    // scale * (Bk + Yk): weight of softmax_v
+    float sbk;   // scale * Bk: taken off the blank logit
+    float syk;   // scale * Yk: taken off the label logit
+    float nl2;   // -lse * log2(e): softmax_v = 2^(x_v*log2e + nl2)
+    int y;       // label of this node's emit arc, -1 if none
+};
+
+// Same association as the upstream CPU path: alpha + beta_next + lp - ll, and the dense softmax
+// term weighted by (Bk + Yk) rather than by e^{alpha+beta-ll}.
+__device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &c, int Tb, int Ub,
+                                              const int *__restrict__ labels, int U1,
+                                              const float *__restrict__ grad_out, int grad_out_stride,
+                                              float grad_scale) {
+    const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+    const float llb = L.ll[c.b];
+    const float a = L.alpha[o];
+    const float2 lp = L.lp[o];
+    const float scale = grad_scale * (grad_out ? grad_out[(size_t)c.b * grad_out_stride] : 1.0f);
+    float bk = 0.0f, yk = 0.0f;
+    NodeCoef n;
+    n.y = -1;
+    if (c.t < Tb - 1)
+        bk = __expf(a + L.beta[o + L.US] + lp.x - llb);  // beta(t+1,u): next diagonal, same column
+    else if (c.u == Ub)
+        bk = __expf(a + lp.x - llb);
+    if (c.u < Ub) {
+        n.y = labels[(size_t)c.b * (U1 - 1) + c.u];
+        yk = __expf(a + L.beta[o + L.US + 1] + lp.y - llb);  // beta(t,u+1): next diagonal, column+1
+    }
+    n.nl2 = -L.lse[o] * kLog2e;
+    n.sa = scale * (bk + yk);
+    n.sbk = scale * bk;
+    n.syk = scale * yk;
+    return n;
+}
+
+template <typename DT>
+__device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, int v0, const NodeCoef &n, int blank) {
+    constexpr int EPC = DT::EPC;
+    float x[EPC];
+    DT::unpack(raw, x);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+        float g = n.sa * __builtin_amdgcn_exp2f(fmaf(x[j], kLog2e, n.nl2));
+        g -= (v0 + j == blank) ? n.sbk : 0.0f;
+        g -= (v0 + j == n.y) ? n.syk : 0.0f;
+        x[j] = g;
+    }
+    return DT::pack(x);
+}
+
+// The whole row is in flight per wave (NCH chunks per lane): few, large read bursts followed by
+// large write bursts per CU measured faster than many small ones at high occupancy.
+template <bool NT, typename P>
+__device__ __forceinline__ u32x4 ld16(const P *p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(const u32x4 &v, u32x4 *p) {
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+template <typename DT, int NCH, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH), k3_waves(NCH))))
+void rnnt_k3_grad(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
     const int *__restrict__ labels, const int *__restrict__ act_lens,
-    const int *__restrict__ label_lens, const float *__restrict__ lse, const float *__restrict__ lpB,
-    const float *__restrict__ lpY, const float *__restrict__ alpha, const float *__restrict__ beta,
-    const float *__restrict__ ll, const float *__restrict__ grad_out, int grad_out_stride,
-    float grad_scale, int maxT, int U1, int V, int blank, int ND, long long total_rows) {
+    const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
+    int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows,
+    int nseg) {
     constexpr int EPC = DT::EPC;
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
     const int nchunks = V / EPC;
+    const long long nitems = total_rows * nseg;  // a work item = NCH*64 consecutive chunks of one node
 
-    for (long long r = wave0; r < total_rows; r += nwaves) {
+    for (long long wi = wave0; wi < nitems; wi += nwaves) {  // host launches one wave per item
+        const long long r = wi / nseg;
+        const int c0 = (int)(wi - r * nseg) * NCH * kWave + lane;
         const RowCoord c = decode_row(r, maxT, U1);
         const int Tb = act_lens[c.b];
         const int Ub = label_lens[c.b];
@@ -451,8 +574,8 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad(
             const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                const int idx = lane + k * kWave;
-                if (idx < nchunks) __builtin_nontemporal_store(z, out4 + idx);
+                const int idx = c0 + k * kWave;
+                if (idx < nchunks) st16<NTS>(z, out4 + idx);
             }
             continue;
         }
@@ -460,57 +583,24 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad(
         u32x4 raw[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int idx = lane + k * kWave;
-            if (idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
+            const int idx = c0 + k * kWave;
+            if (idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
         }
-        // per-node scalars (wave-uniform addresses)
-        const size_t o = skew_index(c.b, c.t, c.u, ND, U1);
-        const float llb = ll[c.b];
-        const float a = alpha[o];
-        const float scale = grad_scale * (grad_out ? grad_out[(size_t)c.b * grad_out_stride] : 1.0f);
-        // Same association as the upstream CPU path: alpha + beta_next + lp - ll, and the dense
-        // softmax term is weighted by (Bk + Yk) rather than by e^{alpha+beta-ll}.
-        float bk = 0.0f, yk = 0.0f;
-        int y = -1;
-        if (c.t < Tb - 1)
-            bk = __expf(a + beta[o + U1] + lpB[o] - llb);  // beta(t+1,u): next diagonal, same column
-        else if (c.u == Ub)
-            bk = __expf(a + lpB[o] - llb);
-        if (c.u < Ub) {
-            y = labels[(size_t)c.b * (U1 - 1) + c.u];
-            yk = __expf(a + beta[o + U1 + 1] + lpY[o] - llb);  // beta(t,u+1): next diagonal, column+1
-        }
-        const float nl2 = -lse[o] * kLog2e;   // softmax_v = 2^(x*log2e + nl2)
-        const float sa = scale * (bk + yk);
-        const float sbk = scale * bk, syk = scale * yk;
+        const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int idx = lane + k * kWave;
-            if (idx < nchunks) {
-                float x[EPC];
-                DT::unpack(raw[k], x);
-                const int v0 = idx * EPC;
-#pragma unroll
-                for (int j = 0; j < EPC; ++j) {
-                    float g = sa * __builtin_amdgcn_exp2f(fmaf(x[j], kLog2e, nl2));
-                    g -= (v0 + j == blank) ? sbk : 0.0f;
-                    g -= (v0 + j == y) ? syk : 0.0f;
-                    x[j] = g;
-                }
-                __builtin_nontemporal_store(DT::pack(x), out4 + idx);
-            }
+            const int idx = c0 + k * kWave;
+            if (idx < nchunks) st16<NTS>(grad_chunk<DT>(raw[k], idx * EPC, n, blank), out4 + idx);
         }
     }
 }
 
 template <typename DT>
-__global__ __launch_bounds__(256) void rnnt_k3_grad_generic(
+__global__ __launch_bounds__(1024) void rnnt_k3_grad_generic(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
     const int *__restrict__ labels, const int *__restrict__ act_lens,
-    const int *__restrict__ label_lens, const float *__restrict__ lse, const float *__restrict__ lpB,
-    const float *__restrict__ lpY, const float *__restrict__ alpha, const float *__restrict__ beta,
-    const float *__restrict__ ll, const float *__restrict__ grad_out, int grad_out_stride,
-    float grad_scale, int maxT, int U1, int V, int blank, int ND, long long total_rows) {
+    const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
+    int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
@@ -524,26 +614,11 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad_generic(
             continue;
         }
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
-        const size_t o = skew_index(c.b, c.t, c.u, ND, U1);
-        const float llb = ll[c.b];
-        const float a = alpha[o];
-        const float scale = grad_scale * (grad_out ? grad_out[(size_t)c.b * grad_out_stride] : 1.0f);
-        float bk = 0.0f, yk = 0.0f;
-        int y = -1;
-        if (c.t < Tb - 1)
-            bk = __expf(a + beta[o + U1] + lpB[o] - llb);
-        else if (c.u == Ub)
-            bk = __expf(a + lpB[o] - llb);
-        if (c.u < Ub) {
-            y = labels[(size_t)c.b * (U1 - 1) + c.u];
-            yk = __expf(a + beta[o + U1 + 1] + lpY[o] - llb);
-        }
-        const float nl2 = -lse[o] * kLog2e;
-        const float sa = scale * (bk + yk);
+        const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
         for (int v = lane; v < V; v += kWave) {
-            float g = sa * __builtin_amdgcn_exp2f(fmaf(DT::to_float(row[v]), kLog2e, nl2));
-            g -= (v == blank) ? scale * bk : 0.0f;
-            g -= (v == y) ? scale * yk : 0.0f;
+            float g = n.sa * __builtin_amdgcn_exp2f(fmaf(DT::to_float(row[v]), kLog2e, n.nl2));
+            g -= (v == blank) ? n.sbk : 0.0f;
+            g -= (v == n.y) ? n.syk : 0.0f;
             out[v] = DT::from_float(g);
         }
     }
@@ -552,28 +627,29 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad_generic(
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-struct Workspace {
-    float *lse, *lpB, *lpY, *alpha, *beta, *ll;
-};
-
 inline size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+inline int row_stride(int maxU) { return (int)align_up((size_t)maxU, kWave); }
 
+// floats in one fp32 plane of the skewed lattice (+1 row of slack: K3 reads beta at o+US+1)
 inline size_t plane_floats(int maxT, int maxU, int B) {
     const size_t ND = (size_t)maxT + maxU - 1;
-    return align_up((size_t)B * ND * (size_t)maxU + (size_t)maxU + 1, 64);  // +row slack for o+U1+1
+    const size_t US = row_stride(maxU);
+    return (size_t)B * (ND + 1) * US + 2 * US;
 }
 
-inline Workspace carve(void *ws, int maxT, int maxU, int B) {
-    const size_t p = plane_floats(maxT, maxU, B);
+// workspace = lse | lp (float2) | alpha | beta | ll[B]; every plane starts 256-byte aligned
+inline Lattice carve(void *ws, int maxT, int maxU, int B) {
+    const size_t p = plane_floats(maxT, maxU, B);  // multiple of 64 floats = 256 bytes
     float *f = static_cast<float *>(ws);
-    Workspace w;
-    w.lse = f;
-    w.lpB = f + p;
-    w.lpY = f + 2 * p;
-    w.alpha = f + 3 * p;
-    w.beta = f + 4 * p;
-    w.ll = f + 5 * p;
-    return w;
+    Lattice L;
+    L.lse = f;
+    L.lp = reinterpret_cast<float2 *>(f + p);
+    L.alpha = f + 3 * p;
+    L.beta = f + 4 * p;
+    L.ll = f + 5 * p;
+    L.ND = maxT + maxU - 1;
+    L.US = row_stride(maxU);
+    return L;
 }
 
 inline int elem_size(int dtype) { return dtype == RNNT_DTYPE_F32 ? 4 : 2; }
@@ -582,7 +658,7 @@ bool check_common(const void *acts, const int *labels, const int *act_lens, cons
                   int V, int B, const void *ws, const rnntOptions &o) {
     if (!acts || !act_lens || !label_lens || !ws) return false;
     if (!labels && o.maxU > 1) return false;
-    if (V <= 0 || B <= 0 || o.maxT <= 0 || o.maxU <= 0) return false;
+    if (V <= 0 || B <= 0 || o.maxT <= 0 || o.maxU <= 0 || o.maxU > 512) return false;
     if (o.blank_label < 0 || o.blank_label >= V) return false;
     if (o.dtype < RNNT_DTYPE_F32 || o.dtype > RNNT_DTYPE_F16) return false;
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
@@ -590,24 +666,42 @@ bool check_common(const void *acts, const int *labels, const int *act_lens, cons
     return true;
 }
 
-// fast path: 16-byte aligned rows and the whole row fits the register-resident instantiations
-constexpr int kMaxNCH = 32;
-inline int pick_nch(const void *p0, const void *p1, int V, int dtype) {
+// Fast path: 16-byte aligned rows.  A node's row is cut into `nseg` segments of NCH*64 chunks, one
+// wave each (K1: nseg <= 4 waves of one workgroup; K3: any nseg, segments are independent).
+struct Tile {
+    int nch;   // chunks per lane, one of kNchSizes; 0 = use the element-granular fallback
+    int nseg;  // segments (waves) per node
+};
+constexpr int kNchSizes[] = {1, 2, 4, 6, 8, 12, 16, 17};
+inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_seg) {
+    Tile t = {0, 0};
     const int epc = 16 / elem_size(dtype);
-    if (V % epc != 0) return 0;
-    if (reinterpret_cast<uintptr_t>(p0) % 16 != 0) return 0;
-    if (p1 && reinterpret_cast<uintptr_t>(p1) % 16 != 0) return 0;
-    const int need = (V / epc + kWave - 1) / kWave;
-    static const int sizes[] = {1, 2, 4, 6, 8, 12, 17, 24, 32};
-    for (int s : sizes)
-        if (need <= s) return s;
-    return 0;
+    if (V % epc != 0) return t;
+    if (reinterpret_cast<uintptr_t>(p0) % 16 != 0) return t;
+    if (p1 && reinterpret_cast<uintptr_t>(p1) % 16 != 0) return t;
+    const int need = (V / epc + kWave - 1) / kWave;  // chunks per lane if one wave took the whole row
+    int nseg = (need + 16) / 17;
+    if (max_seg == 4 && nseg == 3) nseg = 4;  // K1 splits a workgroup of 4 waves evenly
+    if (nseg > max_seg) return t;
+    const int per = (need + nseg - 1) / nseg;
+    for (int sz : kNchSizes)
+        if (per <= sz) {
+            t.nch = sz;
+            t.nseg = nseg;
+            return t;
+        }
+    return t;
 }
 
-inline int stream_grid(long long total_rows) {
-    // grid-stride over lattice nodes: 256 CUs x 8 blocks of 4 waves
-    const long long want = (total_rows + 3) / 4;
-    return (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+// One wave per lattice node, nodes dealt to workgroups in memory order: the resident workgroups
+// then cover one contiguous, advancing window of the logits (and of the gradient), which is what
+// HBM wants.  Measured on config 2: K1 1.45 -> 1.31 ms, K3 3.51 -> 3.14 ms against a 2048-block
+// grid-stride launch.  The kernels keep their grid-stride loop so any grid is valid.
+inline int stream_grid(long long total_rows, int block) {
+    const int wpb = block / kWave;
+    const long long want = (total_rows + wpb - 1) / wpb;
+    const long long cap = 0x7fffffffLL;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
 inline void record(const rnntOptions &o, int i) {
@@ -615,79 +709,93 @@ inline void record(const rnntOptions &o, int i) {
         (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[i]), static_cast<hipStream_t>(o.stream));
 }
 
-#define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(12) M(17) M(24) M(32)
+// Developer knobs for A/B runs (tools/sweep.sh); unset in production, where the defaults below are
+// the measured best on config 2 (profiles/r01_tuning.md).
+inline int tuning_knob(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+#define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)
 
 template <typename DT>
 rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens, const int *label_lens,
-                       int V, int B, const Workspace &w, const rnntOptions &o) {
+                       int V, int B, const Lattice &L, const rnntOptions &o) {
     typedef typename DT::elem E;
     const long long rows = (long long)B * o.maxT * o.maxU;
-    const int ND = o.maxT + o.maxU - 1;
-    const int grid = stream_grid(rows);
+    const int block = 256;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
-    const int nch = pick_nch(acts, nullptr, V, o.dtype);
-    switch (nch) {
-#define CASE(N)                                                                                     \
-    case N:                                                                                         \
-        hipLaunchKernelGGL((rnnt_k1_lse<DT, N>), dim3(grid), dim3(256), 0, st,                      \
-                           static_cast<const E *>(acts), labels, act_lens, label_lens, w.lse, w.lpB, \
-                           w.lpY, o.maxT, o.maxU, V, o.blank_label, ND, rows);                      \
+    const Tile t = pick_tile(acts, nullptr, V, o.dtype, 4);
+    int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
+    const int g = tuning_knob("RNNT_K1_GRID", 0);
+    if (g > 0) grid = g;
+#define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
+#define CASE(N)                                                                                        \
+    case N:                                                                                            \
+        if (t.nseg == 1)                                                                               \
+            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 1>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
+        else if (t.nseg == 2)                                                                          \
+            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 2>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
+        else                                                                                           \
+            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 4>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
         break;
+    switch (t.nch) {
         FOR_EACH_NCH(CASE)
-#undef CASE
         default:
-            hipLaunchKernelGGL((rnnt_k1_lse_generic<DT>), dim3(grid), dim3(256), 0, st,
-                               static_cast<const E *>(acts), labels, act_lens, label_lens, w.lse, w.lpB,
-                               w.lpY, o.maxT, o.maxU, V, o.blank_label, ND, rows);
+            hipLaunchKernelGGL((rnnt_k1_lse_generic<DT>), dim3(grid), dim3(block), 0, st, K1_ARGS);
     }
+#undef CASE
+#undef K1_ARGS
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
+
+#define K3_ARGS                                                                                       \
+    static_cast<const E *>(acts), static_cast<E *>(grads), labels, act_lens, label_lens, L, grad_out, \
+        grad_out_stride, grad_scale, o.maxT, o.maxU, V, o.blank_label, rows
 
 template <typename DT>
 rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const int *act_lens,
                        const int *label_lens, int V, int B, const float *grad_out, int grad_out_stride,
-                       float grad_scale, const Workspace &w, const rnntOptions &o) {
+                       float grad_scale, const Lattice &L, const rnntOptions &o) {
     typedef typename DT::elem E;
     const long long rows = (long long)B * o.maxT * o.maxU;
-    const int ND = o.maxT + o.maxU - 1;
-    const int grid = stream_grid(rows);
+    const int block = tuning_knob("RNNT_K3_BLOCK", 512);  // 8 nodes per workgroup: 3.14 -> 3.04 ms vs 256
     hipStream_t st = static_cast<hipStream_t>(o.stream);
-    const int nch = pick_nch(acts, grads, V, o.dtype);
-    switch (nch) {
-#define CASE(N)                                                                                        \
-    case N:                                                                                            \
-        hipLaunchKernelGGL((rnnt_k3_grad<DT, N>), dim3(grid), dim3(256), 0, st,                        \
-                           static_cast<const E *>(acts), static_cast<E *>(grads), labels, act_lens,    \
-                           label_lens, w.lse, w.lpB, w.lpY, w.alpha, w.beta, w.ll, grad_out,           \
-                           grad_out_stride, grad_scale, o.maxT, o.maxU, V, o.blank_label, ND, rows);   \
+    const Tile t = pick_tile(acts, grads, V, o.dtype, 1 << 20);
+    int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
+    const int g = tuning_knob("RNNT_K3_GRID", 0);
+    if (g > 0) grid = g;
+    const int lds = tuning_knob("RNNT_K3_LDS", 0);  // unused dynamic LDS: caps workgroups per CU
+    switch (t.nch) {
+#define CASE(N)                                                                                       \
+    case N:                                                                                           \
+        hipLaunchKernelGGL((rnnt_k3_grad<DT, N>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg); \
         break;
         FOR_EACH_NCH(CASE)
 #undef CASE
         default:
-            hipLaunchKernelGGL((rnnt_k3_grad_generic<DT>), dim3(grid), dim3(256), 0, st,
-                               static_cast<const E *>(acts), static_cast<E *>(grads), labels, act_lens,
-                               label_lens, w.lse, w.lpB, w.lpY, w.alpha, w.beta, w.ll, grad_out,
-                               grad_out_stride, grad_scale, o.maxT, o.maxU, V, o.blank_label, ND, rows);
+            hipLaunchKernelGGL((rnnt_k3_grad_generic<DT>), dim3(grid), dim3(block), 0, st, K3_ARGS);
     }
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 
-rnntStatus_t launch_k2(const int *act_lens, const int *label_lens, int B, float *costs, const Workspace &w,
+rnntStatus_t launch_k2(const int *act_lens, const int *label_lens, int B, float *costs, const Lattice &L,
                        const rnntOptions &o) {
-    const int ND = o.maxT + o.maxU - 1;
-    const int NW = (o.maxU + kWave - 1) / kWave;
+    const int NW = L.US / kWave;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
-#define K2(N)                                                                                          \
-    hipLaunchKernelGGL((rnnt_k2_lattice<N>), dim3(B), dim3(2 * N * kWave), 0, st, w.lpB, w.lpY, w.alpha, \
-                       w.beta, w.ll, costs, act_lens, label_lens, o.maxU, ND)
+#define K2(N)                                                                                         \
+    hipLaunchKernelGGL((rnnt_k2_lattice<N>), dim3(B), dim3(2 * N * kWave), 0, st, L, costs, act_lens, \
+                       label_lens, o.maxT, o.maxU)
     switch (NW) {
         case 1: K2(1); break;
         case 2: K2(2); break;
         case 3: K2(3); break;
         case 4: K2(4); break;
-        case 5: case 6: K2(6); break;
-        case 7: case 8: K2(8); break;
-        default: return RNNT_STATUS_INVALID_VALUE;  // maxU > 512 labels+1: not supported
+        case 5: K2(5); break;
+        case 6: K2(6); break;
+        case 7: K2(7); break;
+        case 8: K2(8); break;
+        default: return RNNT_STATUS_INVALID_VALUE;  // maxU > 512: not supported
     }
 #undef K2
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
@@ -732,7 +840,7 @@ rnntStatus_t rnnt_forward(const void *acts, const int *labels, const int *act_le
         !costs)
         return RNNT_STATUS_INVALID_VALUE;
     if (reduction < RNNT_REDUCTION_NONE || reduction > RNNT_REDUCTION_SUM) return RNNT_STATUS_INVALID_VALUE;
-    const Workspace w = carve(workspace, options.maxT, options.maxU, minibatch);
+    const Lattice w = carve(workspace, options.maxT, options.maxU, minibatch);
     record(options, 0);
     rnntStatus_t s;
     switch (options.dtype) {
@@ -766,7 +874,7 @@ rnntStatus_t rnnt_backward(const void *acts, void *grads, const int *labels, con
         !grads)
         return RNNT_STATUS_INVALID_VALUE;
     if (grad_out_stride < 0) return RNNT_STATUS_INVALID_VALUE;
-    const Workspace w = carve(const_cast<void *>(workspace), options.maxT, options.maxU, minibatch);
+    const Lattice w = carve(const_cast<void *>(workspace), options.maxT, options.maxU, minibatch);
     record(options, 0);
     rnntStatus_t s;
     switch (options.dtype) {

@@ -61,11 +61,31 @@ def test_small_ragged_vs_oracle(B, T, U, V, seed, reduction):
     check_against_oracle(acts, labels, al, ll, reduction, go)
 
 
-@pytest.mark.parametrize("V", [5, 6, 7, 4234, 4232, 4100, 8200, 8196])
+@pytest.mark.parametrize("V", [5, 6, 7, 4234, 4232, 4100, 4352, 8200, 8196, 16384, 17408, 20000])
 def test_vocab_sizes_and_alignment(V):
-    # V % 4 != 0 exercises the element-granular fallback; 8200 the largest register-resident tile + fallback
+    # V % 4 != 0 -> element-granular fallback; 4352 = exactly 17 chunks/lane; 8200 -> two waves per
+    # node in K1 and two segments in K3; 16384/17408 -> four; 20000 -> K1 fallback, five K3 segments
     acts, labels, al, ll = make_case(2, 9, 4, V, seed=V, ragged=True)
     check_against_oracle(acts, labels, al, ll, "mean", 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V", [64, 4232, 4234, 16384, 40000])
+def test_half_precision_logits(dtype, V):
+    """bf16 / fp16 logits and grads with the fp32 lattice (BASELINE.json configs[4] numerics).
+
+    Tolerance, stated separately from fp32 as north_star asks: the oracle runs in fp32 on the
+    SAME rounded logits; loss within 1e-5 relative (the lattice is fp32 either way); each gradient
+    within one rounding step of its dtype: |g - g_ref| <= 1e-4 + 2^-8 |g_ref| (bf16), 2^-11 (fp16).
+    """
+    acts, labels, al, ll = make_case(3, 12, 5, V, seed=V + 1, ragged=True, sigma=2.0)
+    acts = torch.from_numpy(acts).to(dtype).float().numpy()  # what the kernel will actually see
+    loss, grads = run_gpu(acts, labels, al, ll, "mean", 0.5, dtype=dtype)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    ref_loss, ref_g = oracle.reduce_like_upstream(c, g, "mean", 0.5)
+    np.testing.assert_allclose(loss, ref_loss, rtol=LOSS_RTOL, atol=0)
+    rel = 2.0 ** -8 if dtype is torch.bfloat16 else 2.0 ** -11
+    assert np.all(np.abs(grads - ref_g) <= 1e-4 + rel * np.abs(ref_g))
 
 
 def test_peaked_trained_like():
