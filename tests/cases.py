@@ -33,10 +33,12 @@ def make_case(B, T, U, V, seed=0, ragged=True, sigma=1.0, peaked=False, blank=0,
     return acts, labels, act_lens, label_lens
 
 
+_KAT1_ACTS = [[[[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.6, 0.1, 0.1], [0.1, 0.1, 0.2, 0.8, 0.1]],
+               [[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.1, 0.1], [0.7, 0.1, 0.2, 0.1, 0.1]]]]
+# Known-answer vector recalled from the upstream package's public unit test.
 KAT1 = dict(
-    acts=np.array([[[[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.6, 0.1, 0.1], [0.1, 0.1, 0.2, 0.8, 0.1]],
-                    [[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.1, 0.1], [0.7, 0.1, 0.2, 0.1, 0.1]]]],
-                  dtype=np.float32),
+    acts=np.array(_KAT1_ACTS, dtype=np.float32),
+    acts64=np.array(_KAT1_ACTS, dtype=np.float64),
     labels=np.array([[1, 2]], dtype=np.int32),
     act_lens=np.array([2], dtype=np.int32),
     label_lens=np.array([2], dtype=np.int32),

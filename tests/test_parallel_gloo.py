@@ -1,0 +1,120 @@
+"""The batch-sharded harness (rnnt_amd/parallel.py) on CPU: world_size 2 and 3 over gloo.
+
+The HIP kernels cannot run here, so the per-utterance cost function is injected: an autograd
+wrapper around the CPU oracle.  What is under test is the harness: shard bounds, the single
+all-reduce of per-utterance costs, the fixed-order scalar, and that each rank's gradient equals
+its slice of the unsharded gradient bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from rnnt_amd.parallel import ShardedRNNTLoss, ordered_reduce, shard_batch, shard_bounds  # noqa: E402
+
+
+class OracleCosts(torch.autograd.Function):
+    """[B] per-utterance costs from the CPU oracle, with its gradient."""
+
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank):
+        import oracle
+
+        c, g, _ = oracle.rnnt_loss_c(acts.detach().numpy(), labels.numpy(), act_lens.numpy(),
+                                     label_lens.numpy(), blank=blank, num_threads=1)
+        ctx.save_for_backward(torch.from_numpy(g))
+        return torch.from_numpy(c)
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go.reshape(-1, 1, 1, 1), None, None, None, None
+
+
+def oracle_loss_fn(acts, labels, act_lens, label_lens, blank):
+    return OracleCosts.apply(acts, labels, act_lens, label_lens, blank)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, B, reduction, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cases import make_case
+
+        acts, labels, al, ll = make_case(B, 9, 4, 12, seed=77, ragged=True, sigma=2.0)
+        full = [torch.from_numpy(x) for x in (acts, labels, al, ll)]
+        a, lab, alr, llr = shard_batch(*full, world, rank)
+        a = a.clone().requires_grad_(True)
+        crit = ShardedRNNTLoss(blank=0, reduction=reduction, loss_fn=oracle_loss_fn)
+        loss = crit(a, lab, alr, llr, global_batch=B)
+        if reduction == "none":
+            go = torch.linspace(0.5, 1.5, B)
+            loss.backward(go)
+        else:
+            loss.backward(torch.tensor([0.5]))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=loss.detach().numpy(), grad=a.grad.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,reduction", [(2, 4, "mean"), (2, 5, "sum"), (3, 7, "mean"), (2, 4, "none")])
+def test_sharded_equals_unsharded_bitwise(tmp_path, world, B, reduction):
+    import oracle
+    from cases import make_case
+
+    port = free_port()
+    mp.spawn(worker, args=(world, port, B, reduction, str(tmp_path)), nprocs=world, join=True)
+
+    acts, labels, al, ll = make_case(B, 9, 4, 12, seed=77, ragged=True, sigma=2.0)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll, num_threads=1)
+    if reduction == "none":
+        ref_loss = c
+        ref_g = g * torch.linspace(0.5, 1.5, B).numpy().reshape(B, 1, 1, 1)
+    else:
+        ref_loss = ordered_reduce(torch.from_numpy(c), reduction).numpy()
+        factor = np.float32(1.0 / B) if reduction == "mean" else np.float32(1.0)
+        ref_g = g * (np.float32(0.5) * factor)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        lo, hi = shard_bounds(B, world, r)
+        np.testing.assert_array_equal(z["loss"], ref_loss)       # identical bits on every rank
+        np.testing.assert_array_equal(z["grad"], ref_g[lo:hi])       # and identical gradient bits
+        assert np.all((z["grad"] == 0) == (ref_g[lo:hi] == 0))   # padding stays exactly zero
+
+
+def test_shard_bounds():
+    assert [shard_bounds(7, 3, r) for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
+    assert [shard_bounds(256, 8, r) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    with pytest.raises(ValueError):
+        shard_bounds(2, 3, 0)
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_ordered_reduce_is_sequential_fp32():
+    c = torch.tensor([1e8, 1.0, -1e8, 1.0], dtype=torch.float32)
+    # ((1e8 + 1) - 1e8) + 1 in fp32 = 1, not 2: proves index order, fp32 accumulation
+    assert float(ordered_reduce(c, "sum")[0]) == 1.0
+    assert float(ordered_reduce(c, "mean")[0]) == 0.25
+
+
+def test_needs_process_group():
+    crit = ShardedRNNTLoss(loss_fn=oracle_loss_fn)
+    with pytest.raises(RuntimeError, match="process group"):
+        crit(torch.zeros(1, 1, 1, 2), torch.zeros(1, 0, dtype=torch.int32), torch.ones(1, dtype=torch.int32),
+             torch.zeros(1, dtype=torch.int32))
