@@ -152,6 +152,11 @@ __device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US
     return ((size_t)b * (ND + 1) + (size_t)(t + u)) * US + u;  // +1: K2's junk row
 }
 
+// 16-byte chunks between the previous 128-byte boundary and p
+__device__ __forceinline__ int row_misalign(const void *p) {
+    return (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);
+}
+
 struct Lattice {      // device pointers into the workspace
     float *lse;       // log sum_v exp(x_v) per node
     float2 *lp;       // {lp_blank, lp_label} per node
@@ -206,12 +211,15 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
 
         const typename DT::elem *row = acts + (size_t)(valid ? r : 0) * (size_t)V;
         const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
-        const int c0 = seg * NCH * kWave + lane;
+        // Chunk index of lane 0 is shifted back so that every wave-instruction covers one
+        // 128-byte-aligned KiB of memory whatever the row's own alignment (rows are only 16-byte
+        // aligned: V*elem need not be a multiple of 128).
+        const int c0 = seg * NCH * kWave + lane - row_misalign(row4);
         u32x4 raw[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
-            if (valid && idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
+            if (valid && idx >= 0 && idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
         }
         // blank / label logits: tiny extra loads that hit the lines fetched above
         const int y = (valid && c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
@@ -221,7 +229,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         float m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (valid && c0 + k * kWave < nchunks) {
+            if (valid && c0 + k * kWave >= 0 && c0 + k * kWave < nchunks) {
                 float x[EPC];
                 DT::unpack(raw[k], x);
 #pragma unroll
@@ -248,7 +256,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (valid && c0 + k * kWave < nchunks) {
+            if (valid && c0 + k * kWave >= 0 && c0 + k * kWave < nchunks) {
                 float x[EPC];
                 DT::unpack(raw[k], x);
 #pragma unroll
@@ -565,17 +573,18 @@ void rnnt_k3_grad(
 
     for (long long wi = wave0; wi < nitems; wi += nwaves) {  // host launches one wave per item
         const long long r = wi / nseg;
-        const int c0 = (int)(wi - r * nseg) * NCH * kWave + lane;
         const RowCoord c = decode_row(r, maxT, U1);
         const int Tb = act_lens[c.b];
         const int Ub = label_lens[c.b];
         u32x4 *out4 = reinterpret_cast<u32x4 *>(grads + (size_t)r * (size_t)V);
+        // lane 0 shifted back so each wave-instruction covers a 128-byte-aligned KiB (see K1)
+        const int c0 = (int)(wi - r * nseg) * NCH * kWave + lane - row_misalign(out4);
         if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) {
             const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const int idx = c0 + k * kWave;
-                if (idx < nchunks) st16<NTS>(z, out4 + idx);
+                if (idx >= 0 && idx < nchunks) st16<NTS>(z, out4 + idx);
             }
             continue;
         }
@@ -584,13 +593,13 @@ void rnnt_k3_grad(
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
-            if (idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
+            if (idx >= 0 && idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
         }
         const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
-            if (idx < nchunks) st16<NTS>(grad_chunk<DT>(raw[k], idx * EPC, n, blank), out4 + idx);
+            if (idx >= 0 && idx < nchunks) st16<NTS>(grad_chunk<DT>(raw[k], idx * EPC, n, blank), out4 + idx);
         }
     }
 }
@@ -679,7 +688,8 @@ inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_
     if (V % epc != 0) return t;
     if (reinterpret_cast<uintptr_t>(p0) % 16 != 0) return t;
     if (p1 && reinterpret_cast<uintptr_t>(p1) % 16 != 0) return t;
-    const int need = (V / epc + kWave - 1) / kWave;  // chunks per lane if one wave took the whole row
+    const int need = (V / epc + 7 + kWave - 1) / kWave;  // chunks per lane if one wave took the whole row
+                                                         // (+7: the 128-byte alignment shift)
     int nseg = (need + 16) / 17;
     if (max_seg == 4 && nseg == 3) nseg = 4;  // K1 splits a workgroup of 4 waves evenly
     if (nseg > max_seg) return t;
