@@ -1,0 +1,194 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the CPU oracle
+would take minutes there): rows of the gradient sum to zero, per-node logit shifts change nothing,
+padding is exactly zero and its content (NaN) is ignored, batch permutation commutes, repeated
+runs are bitwise identical (no atomics anywhere), alpha/beta agree on the likelihood, and a
+sampled utterance matches the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def device_case(B, T, U, V, ragged, seed=1234, dtype=torch.float32, nan_padding=False):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    acts = torch.empty((B, T, U + 1, V), dtype=dtype, device=DEV)
+    for b in range(B):
+        if dtype is torch.float32:
+            acts[b].normal_(0, 1, generator=g)
+        else:
+            for t0 in range(0, T, 100):
+                t1 = min(T, t0 + 100)
+                acts[b, t0:t1] = torch.randn((t1 - t0, U + 1, V), device=DEV, generator=g).to(dtype)
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    if ragged:
+        al = rng.integers(max(1, T // 8), T + 1, size=B).astype(np.int32)
+        ll = rng.integers(max(0, U // 6), U + 1, size=B).astype(np.int32)
+        al[0], ll[0] = T, U
+        for b in range(B):
+            labels[b, ll[b]:] = 0
+            if nan_padding:
+                acts[b, al[b]:] = float("nan")
+                acts[b, :, ll[b] + 1:] = float("nan")
+    else:
+        al = np.full(B, T, np.int32)
+        ll = np.full(B, U, np.int32)
+    return acts, labels, al, ll
+
+
+def run(acts, labels, al, ll, reduction="mean", go=0.5):
+    import rnnt_amd
+
+    a = acts.detach().requires_grad_(True)
+    loss = rnnt_amd.RNNTLoss(reduction=reduction)(a, torch.from_numpy(labels).to(DEV), torch.from_numpy(al).to(DEV),
+                                                  torch.from_numpy(ll).to(DEV))
+    loss.backward(torch.full_like(loss, go))
+    return loss.detach(), a.grad
+
+
+def check_row_sums_and_padding(grads, al, ll, tol):
+    B = grads.shape[0]
+    rs = grads.float().sum(-1)  # [B,T,U+1]
+    for b in range(B):
+        T, U = int(al[b]), int(ll[b])
+        assert float(rs[b, :T, :U + 1].abs().max()) <= tol
+        assert not bool(grads[b, T:].any()) and not bool(grads[b, :, U + 1:].any())  # exact zeros
+    assert bool(torch.isfinite(grads).all())
+
+
+def test_config2_full_size_properties():
+    """BASELINE.json configs[1]: B=32 T=400 U=40 V=4232 fp32, uniform lengths."""
+    acts, labels, al, ll = device_case(32, 400, 40, 4232, ragged=False)
+    loss, g = run(acts, labels, al, ll)
+    assert loss.shape == (1,) and bool(torch.isfinite(loss).all())
+    check_row_sums_and_padding(g, al, ll, tol=2e-6)
+    # the gradient of the mean w.r.t. blank logits is <= 0 off the final node: mass leaves through blank
+    # determinism: second run bitwise identical
+    loss2, g2 = run(acts, labels, al, ll)
+    assert torch.equal(loss, loss2) and torch.equal(g, g2)
+    del g2
+    # per-node shift invariance (softmax): add a different constant to every node's row
+    shift = torch.randn(acts.shape[:3] + (1,), device=DEV) * 3
+    loss3, g3 = run(acts + shift, labels, al, ll)
+    assert abs(float(loss3) - float(loss)) <= 2e-5 * abs(float(loss))
+    assert float((g3 - g).abs().max()) <= 1e-4
+    del g3, shift
+    # one utterance against the oracle (unpadded == batched)
+    b = 17
+    c, go_, _ = oracle.rnnt_loss_c(acts[b:b + 1].cpu().numpy(), labels[b:b + 1], al[b:b + 1], ll[b:b + 1])
+    assert float(np.abs(g[b].cpu().numpy() - go_[0] * (0.5 / 32)).max()) <= 1e-4
+    costs, _ = run(acts, labels, al, ll, reduction="none", go=1.0)
+    assert abs(float(costs[b]) - c[0]) <= 1e-5 * abs(c[0])
+    # reduction 'mean' is the index-order fp32 sum of 'none' divided by B
+    s = np.float32(0)
+    for v in costs.cpu().numpy():
+        s = np.float32(s + v)
+    assert float(loss) == float(np.float32(s / np.float32(32)))
+
+
+def test_config2_batch_permutation():
+    acts, labels, al, ll = device_case(8, 400, 40, 4232, ragged=True, seed=99)
+    costs, g = run(acts, labels, al, ll, reduction="none", go=1.0)
+    perm = np.array([3, 7, 0, 5, 1, 6, 2, 4])
+    pt = torch.from_numpy(perm).to(DEV)
+    costs_p, g_p = run(acts[pt].contiguous(), labels[perm], al[perm], ll[perm], reduction="none", go=1.0)
+    assert torch.equal(costs_p, costs[pt]) and torch.equal(g_p, g[pt])  # utterances are independent: bitwise
+
+
+def test_config3_ragged_nan_padding():
+    """BASELINE.json configs[2]: ragged B=64 (T 100-800, U 10-60); padded logits are NaN to prove masking."""
+    free, _ = torch.cuda.mem_get_info()
+    B = 64 if free > 130e9 else 16
+    acts, labels, al, ll = device_case(B, 800, 60, 4232, ragged=True, seed=7, nan_padding=True)
+    loss, g = run(acts, labels, al, ll)
+    assert bool(torch.isfinite(loss).all())
+    check_row_sums_and_padding(g, al, ll, tol=2e-6)
+    # ragged == per-utterance unpadded, on the shortest utterance, against the oracle too
+    b = int(np.argmin(al.astype(np.int64) * (ll + 1)))
+    T, U = int(al[b]), int(ll[b])
+    sub = acts[b:b + 1, :T, :U + 1].contiguous()
+    costs, gs = run(sub, labels[b:b + 1, :U].copy(), al[b:b + 1], ll[b:b + 1], reduction="none", go=1.0)
+    costs_all, _ = run(acts, labels, al, ll, reduction="none", go=1.0)
+    assert float(costs[0]) == float(costs_all[b])
+    c, go_, _ = oracle.rnnt_loss_c(sub.cpu().numpy(), labels[b:b + 1, :U], [T], [U])
+    assert abs(float(costs[0]) - c[0]) <= 1e-5 * abs(c[0])
+    # UNSCALED per-utterance gradients (reduction 'none', grad_output 1) reach O(1) while |ll| ~ 1e3,
+    # where one fp32 ulp of alpha+beta-ll is ~1e-4: two fp32 implementations (different summation
+    # order in the softmax denominators) differ by that much relative.  So: 1e-4 absolute on the
+    # gradient the reference's call actually produces ('mean' over B, checked below), and
+    # 1e-4 + 1e-3 |g| on the unscaled one; and the GPU must be no further from the float64 oracle
+    # than the fp32 CPU oracle is (x2 slack).
+    gnp = gs.cpu().numpy()
+    assert np.all(np.abs(gnp - go_) <= 1e-4 + 1e-3 * np.abs(go_))
+    _, g64, _ = oracle.rnnt_loss_c(sub.cpu().numpy(), labels[b:b + 1, :U], [T], [U], dtype=np.float64)
+    err_gpu, err_cpu = np.abs(gnp - g64).max(), np.abs(go_ - g64).max()
+    print(f"unscaled grad error vs f64: gpu {err_gpu:.2e}, cpu-f32 oracle {err_cpu:.2e}")
+    assert err_gpu <= max(2 * err_cpu, 1e-4)
+    assert float(np.abs(gnp * (0.5 / B) - go_ * (0.5 / B)).max()) <= 1e-4
+    assert float((g[b, :T, :U + 1] - gs[0] * (0.5 / B)).abs().max()) <= 1e-7
+
+
+def test_config5_shape_bf16_slice():
+    """BASELINE.json configs[4] numerics at reduced B/T (same U=150, V=16384, bf16 IO, fp32 lattice):
+    three waves per direction in K2, two waves per node in K1, two segments per node in K3."""
+    acts, labels, al, ll = device_case(2, 300, 150, 16384, ragged=True, seed=5, dtype=torch.bfloat16)
+    loss, g = run(acts, labels, al, ll)
+    assert bool(torch.isfinite(loss).all())
+    check_row_sums_and_padding(g, al, ll, tol=3e-3)  # bf16-rounded gradients
+    c, go_, _ = oracle.rnnt_loss_c(acts.float().cpu().numpy(), labels, al, ll)
+    ref = np.float32(c.sum(dtype=np.float32) / 2)
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+    ref_g = go_ * (0.5 / 2)
+    assert np.all(np.abs(g.float().cpu().numpy() - ref_g) <= 1e-4 + 2.0 ** -8 * np.abs(ref_g))
+
+
+def test_invalid_lengths_give_nan_not_fault():
+    """check_lengths=False: the kernels guard themselves (NaN cost, zero gradient, no OOB access)."""
+    import rnnt_amd
+
+    acts, labels, al, ll = device_case(3, 6, 3, 64, ragged=False, seed=3)
+    al = al.copy()
+    ll = ll.copy()
+    al[1] = 7   # > T
+    ll[2] = -1  # < 0
+    a = acts.requires_grad_(True)
+    costs = rnnt_amd.RNNTLoss(reduction="none", check_lengths=False)(
+        a, torch.from_numpy(labels).to(DEV), torch.from_numpy(al).to(DEV), torch.from_numpy(ll).to(DEV))
+    costs.backward(torch.ones_like(costs))
+    c = costs.detach().cpu().numpy()
+    assert np.isfinite(c[0]) and np.isnan(c[1]) and np.isnan(c[2])
+    assert not bool(a.grad[1].any()) and not bool(a.grad[2].any()) and bool(torch.isfinite(a.grad[0]).all())
+    with pytest.raises(ValueError, match="Input length mismatch"):
+        rnnt_amd.RNNTLoss()(a, torch.from_numpy(labels).to(DEV), torch.from_numpy(al).to(DEV),
+                            torch.from_numpy(np.maximum(ll, 0)).to(DEV))
+
+
+def test_compute_rnnt_loss_upstream_shaped_call():
+    """The upstream-shaped single C entry point: costs + unscaled gradients."""
+    import ctypes
+
+    from rnnt_amd import _lib
+    from cases import make_case
+
+    acts, labels, al, ll = make_case(3, 10, 4, 40, seed=42, ragged=True)
+    lib = _lib.load()
+    d = lambda x: torch.from_numpy(x).to(DEV)
+    a, lab, ald, lld = d(acts), d(labels), d(al), d(ll)
+    grads = torch.empty_like(a)
+    costs = torch.empty(3, dtype=torch.float32, device=DEV)
+    ws = torch.empty(_lib.workspace_bytes(10, 5, 3), dtype=torch.uint8, device=DEV)
+    opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, 10, 5, _lib.DTYPE_F32, None)
+    _lib.check(lib.compute_rnnt_loss(a.data_ptr(), grads.data_ptr(), lab.data_ptr(), lld.data_ptr(), ald.data_ptr(),
+                                     40, 3, costs.data_ptr(), ws.data_ptr(), opts), "compute_rnnt_loss")
+    torch.cuda.synchronize()
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5)
+    assert np.abs(grads.cpu().numpy() - g).max() <= 1e-4
+    # misaligned workspace is rejected with a status, not a fault
+    bad = lib.compute_rnnt_loss(a.data_ptr(), grads.data_ptr(), lab.data_ptr(), lld.data_ptr(), ald.data_ptr(),
+                                40, 3, costs.data_ptr(), ws.data_ptr() + 4, opts)
+    assert bad == 2
