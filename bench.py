@@ -111,9 +111,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-b", type=int, default=16)
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the sharded harness (RCCL all-reduce of costs) even with one rank")
     ap.add_argument("--no-check-lengths", action="store_true",
                     help="skip the host-side length check (fully asynchronous forward)")
     args = ap.parse_args()
+
+    # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout.
+    # Point fd 1 at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,9 +141,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X; rnnt_amd has no CPU path")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
 
     w = dict(WORKLOADS[args.workload])
     B = w["B"]
@@ -143,7 +153,7 @@ def main():
     acts.requires_grad_(True)
     go = torch.full((1,), 0.5, dtype=torch.float32, device=dev)  # grad_output != 1 exercises the fused scale
 
-    if world > 1:
+    if sharded:
         crit = rnnt_amd.ShardedRNNTLoss(blank=0, reduction="mean")
 
         def step():
@@ -162,7 +172,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -186,7 +196,7 @@ def main():
     loss_val = float(loss.detach().cpu()[0])
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
 
@@ -219,7 +229,7 @@ def main():
                         f"{'ragged' if w['ragged'] else 'uniform'} lengths, N(0,1) logits, grad_output=0.5, "
                         f"reduction=mean",
             "global_batch": B * world,
-            "parallelism": f"batch-sharded x{world}, all-reduce of per-utterance costs" if world > 1 else "single GPU",
+            "parallelism": f"batch-sharded x{world}, all-reduce of per-utterance costs" if sharded else "single GPU",
             "check_lengths": not args.no_check_lengths,
         },
         "roofline": {
@@ -255,9 +265,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.cpu_sample_b, args.cpu_reps)
     elif rank == 0:
         out["cpu_baseline"] = None
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

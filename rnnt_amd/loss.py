@@ -76,16 +76,38 @@ def certify_inputs(acts, labels, act_lens, label_lens, check_lengths=True):
     if labels.shape[1] != acts.shape[2] - 1:
         raise ValueError("Output length mismatch")  # labels must be [B, U] for acts [B, T, U+1, V]
     if check_lengths:
-        # One small D2H copy (upstream pays the same sync for its torch.max checks).  Upstream
-        # demands equality; a batch shard of a padded batch legitimately has T > max(lengths)
-        # (SURVEY.md §4, §8b), so the tensor only has to be large enough.
-        lens = torch.cat((act_lens.reshape(-1), label_lens.reshape(-1))).cpu()
-        B = acts.shape[0]
-        al, ll = lens[:B], lens[B:]
-        if int(al.max()) > acts.shape[1] or int(al.min()) < 1:
-            raise ValueError("Input length mismatch")
-        if int(ll.max()) + 1 > acts.shape[2] or int(ll.min()) < 0:
-            raise ValueError("Output length mismatch")
+        _validate_lengths(*_start_length_fetch(acts, act_lens, label_lens))
+
+
+def _start_length_fetch(acts, act_lens, label_lens):
+    """Enqueue a copy of both length vectors to pinned host memory; returns what the check needs.
+
+    Upstream synchronises on ``torch.max(lengths)`` before its native call.  Here the copy is
+    enqueued BEFORE the kernels and waited for AFTER they are launched, so the host check never
+    drains the stream (the kernels guard themselves against bad lengths, so launching first is safe).
+    """
+    B = acts.shape[0]
+    lens = torch.cat((act_lens.reshape(-1), label_lens.reshape(-1)))
+    if lens.is_cuda:
+        host = torch.empty(2 * B, dtype=torch.int32, pin_memory=True)
+        host.copy_(lens, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(lens.device))
+    else:
+        host, ev = lens, None
+    return host, ev, B, acts.shape[1], acts.shape[2]
+
+
+def _validate_lengths(host, ev, B, T, U1):
+    """Upstream demands equality; a batch shard of a padded batch legitimately has T > max(lengths)
+    (SURVEY.md §4, §8b), so the tensor only has to be large enough."""
+    if ev is not None:
+        ev.synchronize()
+    al, ll = host[:B], host[B:]
+    if int(al.max()) > T or int(al.min()) < 1:
+        raise ValueError("Input length mismatch")
+    if int(ll.max()) + 1 > U1 or int(ll.min()) < 0:
+        raise ValueError("Output length mismatch")
 
 
 class _RNNTLossFunction(torch.autograd.Function):
@@ -179,9 +201,13 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", che
             raise RuntimeError(f"{name} must be on the same device as acts ({acts.device}), got {t.device}")
     if not (0 <= int(blank) < acts.shape[3]):
         raise ValueError("blank label out of range")
-    if check_lengths:
-        certify_inputs(acts, labels, act_lens, label_lens, check_lengths=True)
-    return _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+    if not check_lengths:
+        return _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+    with torch.cuda.device(acts.device):
+        pending = _start_length_fetch(acts, act_lens, label_lens)
+        loss = _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+        _validate_lengths(*pending)  # raises ValueError like upstream; the launched kernels were harmless
+    return loss
 
 
 class RNNTLoss(torch.nn.Module):
