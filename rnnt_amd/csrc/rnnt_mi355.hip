@@ -158,7 +158,8 @@ __device__ __forceinline__ int row_misalign(const void *p) {
 }
 
 struct Lattice {      // device pointers into the workspace
-    float *lse;       // log sum_v exp(x_v) per node
+    float2 *ml;       // {max_v x_v, log sum_v exp(x_v - max)} per node, kept apart: lse = m + l would
+                      // round to ulp(|m|) and cost K3 that much relative accuracy on offset logits
     float2 *lp;       // {lp_blank, lp_label} per node
     float *alpha;
     float *beta;
@@ -252,7 +253,6 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         }
         // all -inf row (or +inf max): avoid inf-inf; the result is NaN/-inf downstream as in torch
         const float mm = (m == -INFINITY || m == INFINITY) ? 0.0f : m;
-        const float mneg = -mm * kLog2e;
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -260,7 +260,8 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                 float x[EPC];
                 DT::unpack(raw[k], x);
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) s += __builtin_amdgcn_exp2f(fmaf(x[j], kLog2e, mneg));
+                for (int j = 0; j < EPC; ++j) s += __builtin_amdgcn_exp2f((x[j] - mm) * kLog2e);  // subtract first:
+                // x*log2e - max*log2e would lose ulp(|x|*log2e) when the logits carry a large common offset
             }
         }
         s = wave_sum(s);
@@ -274,7 +275,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         if (valid && seg == 0 && lane == 0) {
             const float logs = __logf(s);
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
-            L.lse[o] = mm + logs;
+            L.ml[o] = make_float2(mm, logs);
             // same association as torch.log_softmax on the upstream CPU path: (x - max) - log(sum)
             L.lp[o] = make_float2((xb - mm) - logs, (xy - mm) - logs);
         }
@@ -302,14 +303,14 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
         const float mm = (m == -INFINITY || m == INFINITY) ? 0.0f : m;
         float s = 0.0f;
         for (int v = lane; v < V; v += kWave)
-            s += __builtin_amdgcn_exp2f(fmaf(DT::to_float(row[v]), kLog2e, -mm * kLog2e));
+            s += __builtin_amdgcn_exp2f((DT::to_float(row[v]) - mm) * kLog2e);
         s = wave_sum(s);
         if (lane == 0) {
             const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
             const float logs = __logf(s);
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
-            L.lse[o] = mm + logs;
+            L.ml[o] = make_float2(mm, logs);
             L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (xy - mm) - logs);
         }
     }
@@ -339,7 +340,10 @@ __device__ __forceinline__ float wave_shift_down(float v, float fill) {  // lane
 __device__ __forceinline__ float log_add_exp(float a, float b) {
     const float big = fmaxf(a, b);
     const float d = fminf(fminf(a, b) - big, 0.0f);
-    return big + kLn2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(d * kLog2e));
+    const float r = big + kLn2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(d * kLog2e));
+    // v_max/v_min return the other operand for a NaN; the loss must surface a NaN logit as a NaN
+    // cost (bin/train.py:36-41 skips the update on it), as the upstream helper does.
+    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;
 }
 
 constexpr int kPF = 16;  // diagonals per register set; two sets ping-pong, so 16..32 rows are in flight
@@ -494,7 +498,8 @@ struct NodeCoef {
     float sa;    // scale * (Bk + Yk): weight of softmax_v
     float sbk;   // scale * Bk: taken off the blank logit
     float syk;   // scale * Yk: taken off the label logit
-    float nl2;   // -lse * log2(e): softmax_v = 2^(x_v*log2e + nl2)
+    float m, l;  // softmax_v = 2^((x_v - m)*log2e - l*log2e): x - max first (as torch.log_softmax), so a
+                 // large common offset of the logits costs nothing
     int y;       // label of this node's emit arc, -1 if none
 };
 
@@ -520,24 +525,39 @@ __device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &
         n.y = labels[(size_t)c.b * (U1 - 1) + c.u];
         yk = __expf(a + L.beta[o + L.US + 1] + lp.y - llb);  // beta(t,u+1): next diagonal, column+1
     }
-    n.nl2 = -L.lse[o] * kLog2e;
+    const float2 ml = L.ml[o];
+    n.m = ml.x;
+    n.l = ml.y;
     n.sa = scale * (bk + yk);
     n.sbk = scale * bk;
     n.syk = scale * yk;
     return n;
 }
 
+// One 16-byte chunk of a node's row.  The two sparse corrections (blank and label logit) touch one
+// lane of one wave-instruction each; `hit_b` / `hit_y` are wave-uniform ("this instruction holds
+// it"), so the element-wise part stays at sub, fma, exp2, mul per logit — K3 at two waves per SIMD
+// turned out to be sensitive to VALU work (+2 ops per logit cost 7 %).
 template <typename DT>
-__device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, int v0, const NodeCoef &n, int blank) {
+__device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, const NodeCoef &n, float nl2, bool hit_b,
+                                            int lane_b, bool hit_y, int lane_y, int lane, int blank) {
     constexpr int EPC = DT::EPC;
     float x[EPC];
     DT::unpack(raw, x);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-        float g = n.sa * __builtin_amdgcn_exp2f(fmaf(x[j], kLog2e, n.nl2));
-        g -= (v0 + j == blank) ? n.sbk : 0.0f;
-        g -= (v0 + j == n.y) ? n.syk : 0.0f;
-        x[j] = g;
+    for (int j = 0; j < EPC; ++j) x[j] = n.sa * __builtin_amdgcn_exp2f(fmaf(x[j] - n.m, kLog2e, nl2));
+    if (hit_b) {
+        asm volatile("; blank-logit correction" ::: "memory");  // keeps this a (scalar) branch: the
+        // compiler otherwise if-converts it into 2 VALU ops per logit on every chunk
+        const float sub = (lane == lane_b) ? n.sbk : 0.0f;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) x[j] -= (j == (blank & (EPC - 1))) ? sub : 0.0f;
+    }
+    if (hit_y) {
+        asm volatile("; label-logit correction" ::: "memory");
+        const float sub = (lane == lane_y) ? n.syk : 0.0f;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) x[j] -= (j == (n.y & (EPC - 1))) ? sub : 0.0f;
     }
     return DT::pack(x);
 }
@@ -596,10 +616,20 @@ void rnnt_k3_grad(
             if (idx >= 0 && idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
         }
         const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
+        const float nl2 = -n.l * kLog2e;  // softmax_v = 2^((x_v - m)*log2e - l*log2e)
+        // which wave-instruction k / lane holds the blank and the label logit (wave-uniform)
+        const int base = __builtin_amdgcn_readfirstlane(c0 - lane);
+        const int rel_b = blank / EPC - base;
+        const int rel_y = (n.y >= 0 ? n.y / EPC : -(1 << 20)) - base;
+        const int kb = __builtin_amdgcn_readfirstlane(rel_b >= 0 ? rel_b >> 6 : -1);
+        const int ky = __builtin_amdgcn_readfirstlane(rel_y >= 0 ? rel_y >> 6 : -1);
+        const int lane_b = rel_b & (kWave - 1), lane_y = rel_y & (kWave - 1);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
-            if (idx >= 0 && idx < nchunks) st16<NTS>(grad_chunk<DT>(raw[k], idx * EPC, n, blank), out4 + idx);
+            if (idx >= 0 && idx < nchunks)
+                st16<NTS>(grad_chunk<DT>(raw[k], n, nl2, k == kb, lane_b, k == ky, lane_y, lane, blank),
+                          out4 + idx);
         }
     }
 }
@@ -625,7 +655,7 @@ __global__ __launch_bounds__(1024) void rnnt_k3_grad_generic(
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
         for (int v = lane; v < V; v += kWave) {
-            float g = n.sa * __builtin_amdgcn_exp2f(fmaf(DT::to_float(row[v]), kLog2e, n.nl2));
+            float g = n.sa * __builtin_amdgcn_exp2f(fmaf(DT::to_float(row[v]) - n.m, kLog2e, -n.l * kLog2e));
             g -= (v == blank) ? n.sbk : 0.0f;
             g -= (v == n.y) ? n.syk : 0.0f;
             out[v] = DT::from_float(g);
@@ -646,16 +676,16 @@ inline size_t plane_floats(int maxT, int maxU, int B) {
     return (size_t)B * (ND + 1) * US + 2 * US;
 }
 
-// workspace = lse | lp (float2) | alpha | beta | ll[B]; every plane starts 256-byte aligned
+// workspace = {m,l} (float2) | lp (float2) | alpha | beta | ll[B]; every plane starts 256-byte aligned
 inline Lattice carve(void *ws, int maxT, int maxU, int B) {
     const size_t p = plane_floats(maxT, maxU, B);  // multiple of 64 floats = 256 bytes
     float *f = static_cast<float *>(ws);
     Lattice L;
-    L.lse = f;
-    L.lp = reinterpret_cast<float2 *>(f + p);
-    L.alpha = f + 3 * p;
-    L.beta = f + 4 * p;
-    L.ll = f + 5 * p;
+    L.ml = reinterpret_cast<float2 *>(f);
+    L.lp = reinterpret_cast<float2 *>(f + 2 * p);
+    L.alpha = f + 4 * p;
+    L.beta = f + 5 * p;
+    L.ll = f + 6 * p;
     L.ND = maxT + maxU - 1;
     L.US = row_stride(maxU);
     return L;
@@ -834,7 +864,7 @@ int rnnt_mi355_abi_version(void) { return kAbiVersion; }
 rnntStatus_t rnnt_get_workspace_size(int maxT, int maxU, int minibatch, size_t *size_bytes) {
     if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
     if (maxU > 512) return RNNT_STATUS_INVALID_VALUE;
-    *size_bytes = (5 * plane_floats(maxT, maxU, minibatch) + align_up((size_t)minibatch, 64)) * sizeof(float);
+    *size_bytes = (6 * plane_floats(maxT, maxU, minibatch) + align_up((size_t)minibatch, 64)) * sizeof(float);
     return RNNT_STATUS_SUCCESS;
 }
 

@@ -102,3 +102,37 @@ def test_config1_shape_vs_oracle():
 def test_nonzero_blank():
     acts, labels, al, ll = make_case(3, 11, 6, 40, seed=31, ragged=True, blank=7)
     check_against_oracle(acts, labels, al, ll, "mean", 1.0, blank=7)
+
+
+def test_labels_equal_to_blank_are_allowed():
+    # upstream does not forbid y == blank; both sparse gradient terms then land on the same logit
+    acts, labels, al, ll = make_case(3, 9, 5, 12, seed=41, ragged=True)
+    labels[0, 1] = 0
+    labels[1, 0] = 0
+    labels[2, :] = 0
+    check_against_oracle(acts, labels, al, ll, "mean", 1.0)
+
+
+def test_masked_vocabulary_entries_minus_inf():
+    acts, labels, al, ll = make_case(2, 8, 4, 20, seed=43, ragged=True)
+    acts[:, :, :, 17:] = -np.inf          # never a label (labels < 17 below), never blank
+    labels = np.minimum(labels, 16).astype(np.int32)
+    loss, grads = check_against_oracle(acts, labels, al, ll, "mean", 1.0)
+    assert np.isfinite(loss).all() and np.all(grads[..., 17:] == 0)
+
+
+def test_extreme_logit_scale():
+    acts, labels, al, ll = make_case(2, 10, 4, 33, seed=44, ragged=True, sigma=30.0)
+    acts += 1e4                            # large common offset: needs the max subtraction
+    check_against_oracle(acts, labels, al, ll, "mean", 1.0)
+
+
+def test_nan_logit_gives_nan_loss_not_an_exception():
+    # bin/train.py:36-41 expects to SEE a NaN loss and skip the update
+    acts, labels, al, ll = make_case(2, 6, 3, 10, seed=45, ragged=False)
+    acts[1, 2, 1, 4] = np.nan
+    loss, grads = run_gpu(acts, labels, al, ll, "none", np.ones(2, np.float32))
+    assert np.isfinite(loss[0]) and np.isnan(loss[1])
+    assert np.isfinite(grads[0]).all()
+    loss_mean, _ = run_gpu(acts, labels, al, ll, "mean")
+    assert np.isnan(loss_mean[0])

@@ -1,3 +1,3 @@
 #!/bin/bash
 run() { env "$@" timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['stages_ms'])" || exit 1; }
-for i in 1 2; do run A=base; run RNNT_AMD_LIB=$PWD/gpurun_tmp/lib_k3bar.so; run RNNT_AMD_LIB=$PWD/gpurun_tmp/lib_k3bar.so RNNT_K3_BLOCK=256; done
+for i in 1 2 3; do run A=new; run RNNT_AMD_LIB=$PWD/gpurun_tmp/lib_head.so; done
