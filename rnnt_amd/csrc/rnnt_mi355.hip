@@ -31,7 +31,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kAbiVersion = 1;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
@@ -70,10 +72,9 @@ struct BF16 {
         }
     }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-        // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
-        const __bf16 a = (__bf16)lo, b = (__bf16)hi;
-        return (unsigned)__builtin_bit_cast(unsigned short, a) |
-               ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        // one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN) for the pair
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
     }
     static __device__ __forceinline__ u32x4 pack(const float (&x)[EPC]) {
         u32x4 r;
@@ -99,9 +100,8 @@ struct F16 {
         }
     }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-        const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-        return (unsigned)__builtin_bit_cast(unsigned short, a) |
-               ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
     }
     static __device__ __forceinline__ u32x4 pack(const float (&x)[EPC]) {
         u32x4 r;
@@ -179,11 +179,18 @@ struct Lattice {      // device pointers into the workspace
 // 3.07 ms at 2 waves/SIMD (one 512-thread workgroup per CU) against 3.17 at 4.  Fewer, larger
 // bursts per CU suit HBM better than maximum occupancy; smaller rows get more waves to keep
 // roughly the same bytes in flight per CU.
-constexpr int k1_waves(int nch) { return nch >= 16 ? 3 : nch >= 12 ? 4 : nch >= 8 ? 6 : 8; }
-constexpr int k3_waves(int nch) { return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 6 : 8; }
+// epc = elements per 16-byte chunk.  16-bit logits carry twice the VALU work per byte: K1 then wants
+// one more wave per SIMD (config 5: 18.8 -> 17.9 ms); K3 still runs best at 2 (38.2 vs 40.0 at 3).
+[[maybe_unused]] constexpr int k1_waves(int nch, int epc) {
+    return nch >= 16 ? (epc > 4 ? 4 : 3) : nch >= 12 ? 4 : nch >= 8 ? 6 : 8;
+}
+[[maybe_unused]] constexpr int k3_waves(int nch, int epc) {
+    (void)epc;
+    return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 6 : 8;
+}
 
 template <typename DT, int NCH, int WPR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH), k1_waves(NCH))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC), k1_waves(NCH, DT::EPC))))
 void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ labels,
                                                    const int *__restrict__ act_lens,
@@ -544,8 +551,18 @@ __device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, const NodeCoef &n,
     constexpr int EPC = DT::EPC;
     float x[EPC];
     DT::unpack(raw, x);
+    // two logits per VALU instruction (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32); only exp2 is scalar
+    const f32x2 m2 = {n.m, n.m}, k2 = {kLog2e, kLog2e}, n2 = {nl2, nl2}, sa2 = {n.sa, n.sa};
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) x[j] = n.sa * __builtin_amdgcn_exp2f(fmaf(x[j] - n.m, kLog2e, nl2));
+    for (int j = 0; j < EPC; j += 2) {
+        f32x2 v = {x[j], x[j + 1]};
+        v = __builtin_elementwise_fma(v - m2, k2, n2);
+        v.x = __builtin_amdgcn_exp2f(v.x);
+        v.y = __builtin_amdgcn_exp2f(v.y);
+        v = v * sa2;
+        x[j] = v.x;
+        x[j + 1] = v.y;
+    }
     if (hit_b) {
         asm volatile("; blank-logit correction" ::: "memory");  // keeps this a (scalar) branch: the
         // compiler otherwise if-converts it into 2 VALU ops per logit on every chunk
@@ -577,7 +594,7 @@ __device__ __forceinline__ void st16(const u32x4 &v, u32x4 *p) {
 }
 
 template <typename DT, int NCH, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH), k3_waves(NCH))))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH, DT::EPC), k3_waves(NCH, DT::EPC))))
 void rnnt_k3_grad(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
     const int *__restrict__ labels, const int *__restrict__ act_lens,
