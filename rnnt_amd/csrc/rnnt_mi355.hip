@@ -284,7 +284,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             L.ml[o] = make_float2(mm, logs);
             // same association as torch.log_softmax on the upstream CPU path: (x - max) - log(sum)
-            L.lp[o] = make_float2((xb - mm) - logs, (xy - mm) - logs);
+            L.lp[o] = make_float2((xb - mm) - logs, (c.u < Ub) ? (xy - mm) - logs : -INFINITY);  // no emit arc at u = U
         }
     }
 }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
             L.ml[o] = make_float2(mm, logs);
-            L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (xy - mm) - logs);
+            L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (c.u < Ub) ? (xy - mm) - logs : -INFINITY);
         }
     }
 }
@@ -326,9 +326,17 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
 // ---------------------------------------------------------------------------------------------
 // K2: alpha / beta over anti-diagonals.  
 // Latency-bound: T+U dependent steps.  Block = 2*NW waves; waves [0,NW) alpha, [NW,2NW) beta.
-// The inner loop is branch-free: every lane loads and stores a (possibly unused) slot of its
-// utterance's skewed plane each step, and invalid lanes carry -inf, so the compiler can keep
-// kPF diagonals of {lp_blank, lp_label} in flight behind counted s_waitcnt vmcnt(N).
+// Lane = u; on diagonal d the lane owns node (d-u, u):
+//   alpha(t,u) = logaddexp(alpha(t-1,u) + lp_blank(t-1,u), alpha(t,u-1) + lp_label(t,u-1))
+//   beta(t,u)  = logaddexp(beta(t+1,u) + lp_blank(t,u),    beta(t,u+1) + lp_label(t,u))
+// (the sums and their order are those of the upstream CPU helper, so the fp32 rounding follows
+// it).  The own-column operand is the lane's previous value, the neighbour's arrives by a
+// one-lane DPP whole-wave shift (through a two-slot LDS cell across a wave edge).  The loop is
+// branch-free and needs no validity selects: a lane holds -inf until its column enters the
+// lattice, every load is clamped to a valid node of the lane's own column (so no uninitialised
+// slot is ever added to a -inf), lp_label is -inf at u = U, and whatever a lane computes after
+// leaving the lattice only reaches lanes that have left it too.  kPF diagonals of
+// {lp_blank, lp_label} per register set, two sets ping-pong behind counted s_waitcnt vmcnt.
 // ---------------------------------------------------------------------------------------------
 // DPP whole-wave shifts by one lane (GFX9 dpp_ctrl wave_shr:1 = 0x138, wave_shl:1 = 0x130).
 // Lanes with no source keep `fill`.
@@ -377,88 +385,71 @@ __global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(Lattice L, flo
         }
         return;
     }
-    const int nd = T + U;                                     // diagonals 0 .. nd-1
+    const int nd = T + U;                                           // diagonals 0 .. nd-1
     const int nsteps = (nd + 2 * kPF - 1) / (2 * kPF) * (2 * kPF);  // whole groups; surplus steps
-    const int junk = L.ND;                                    // store into the utterance's junk row
+    const int junk = L.ND;                                          // store into the utterance's junk row
     const size_t base = (size_t)b * (L.ND + 1) * US;
-    const float2 *__restrict__ lp = L.lp + base + u;
-    const bool col_ok = (u <= U);
+    // loads: this lane's column (clamped into the lattice), rows clamped to that column's nodes
+    const int uc = min(u, U);
+    const float2 *__restrict__ lpc = L.lp + base + uc;
+    const int row_lo = uc, row_hi = uc + T - 1;
+    auto row_of = [&](int d) { return (size_t)min(max(d, row_lo), row_hi) * US; };
     const float NEG = -INFINITY;
 
     if (dir == 0) {
-        // ---- alpha: step d consumes row d-1: lp_blank(t-1,u) from column u, lp_label(t,u-1) from column u-1
         float *__restrict__ out = L.alpha + base + u;
-        const float2 *__restrict__ lpl = lp - (u > 0 ? 1 : 0);  // column u-1 (NW > 1 only)
-        float a_prev = NEG, a_last = NEG;
-        auto row_of = [&](int d) { return (size_t)min(max(d - 1, 0), nd - 1) * US; };
-        auto step = [&](int d, const float2 cur, float lpy_left) {
-            if (NW == 1) lpy_left = wave_shift_up(cur.y, 0.0f);
-            float left = wave_shift_up(a_prev, NEG);
+        float up = (u == 0) ? 0.0f : NEG;  // alpha(t-1,u) + lp_blank(t-1,u); a virtual 0 enters (0,0)
+        float right = NEG;                 // alpha(t,u) + lp_label(t,u), for lane u+1
+        float lik = NEG;
+        auto step = [&](int d, const float2 cur) {
+            float left = wave_shift_up(right, NEG);
             if (NW > 1) {
                 const float edge = xch[0][(d + 1) & 1][w > 0 ? w - 1 : 0];  // written at step d-1
-                left = (lane == 0 && w > 0) ? edge : left;
+                if (lane == 0 && w > 0 && d > 0) left = edge;
             }
-            const int t = d - u;
-            const float up_term = (t > 0) ? a_prev + cur.x : NEG;
-            const float left_term = (u > 0 && d > 0) ? left + lpy_left : NEG;
-            float a = log_add_exp(left_term, up_term);
-            a = (d == 0 && u == 0) ? 0.0f : a;
-            a = (col_ok && t >= 0 && t < T) ? a : NEG;
+            const float a = log_add_exp(left, up);
             out[(size_t)(d < nd ? d : junk) * US] = a;
-            a_prev = a;
-            a_last = (d == nd - 1) ? a : a_last;
+            up = a + cur.x;
+            right = a + cur.y;
+            if (d == nd - 1) lik = up;  // wave-uniform; lane U: alpha(T-1,U) + lp_blank(T-1,U)
             if (NW > 1) {
-                if (lane == kWave - 1) xch[0][d & 1][w] = a;
+                if (lane == kWave - 1) xch[0][d & 1][w] = right;
                 __syncthreads();
             }
         };
         float2 ra[kPF], rb[kPF];
-        float la[NW > 1 ? kPF : 1], lb[NW > 1 ? kPF : 1];
 #pragma unroll
-        for (int i = 0; i < kPF; ++i) {
-            ra[i] = lp[row_of(i)];
-            if (NW > 1) la[i] = lpl[row_of(i)].y;
-        }
+        for (int i = 0; i < kPF; ++i) ra[i] = lpc[row_of(i)];
         for (int d0 = 0; d0 < nsteps; d0 += 2 * kPF) {
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {  // consume set A, refill set B for steps d0+kPF ..
-                rb[i] = lp[row_of(d0 + kPF + i)];
-                if (NW > 1) lb[i] = lpl[row_of(d0 + kPF + i)].y;
-                step(d0 + i, ra[i], NW > 1 ? la[i] : 0.0f);
+                rb[i] = lpc[row_of(d0 + kPF + i)];
+                step(d0 + i, ra[i]);
             }
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {  // consume set B, refill set A for steps d0+2*kPF ..
-                ra[i] = lp[row_of(d0 + 2 * kPF + i)];
-                if (NW > 1) la[i] = lpl[row_of(d0 + 2 * kPF + i)].y;
-                step(d0 + kPF + i, rb[i], NW > 1 ? lb[i] : 0.0f);
+                ra[i] = lpc[row_of(d0 + 2 * kPF + i)];
+                step(d0 + kPF + i, rb[i]);
             }
         }
-        // the last diagonal holds alpha(T-1,U) in lane u == U
         if (u == U) {
-            const float v = a_last + lp[(size_t)(nd - 1) * US].x;
-            L.ll[b] = v;
-            costs[b] = -v;
+            L.ll[b] = lik;
+            costs[b] = -lik;
         }
     } else {
-        // ---- beta: step s handles diagonal d = nd-1-s and consumes row d, column u
         float *__restrict__ out = L.beta + base + u;
-        float b_prev = NEG;
-        auto row_of = [&](int s) { return (size_t)max(nd - 1 - s, 0) * US; };
+        float down = (u == U) ? 0.0f : NEG;  // beta(t+1,u); a virtual 0 leaves (T-1,U) through blank
         auto step = [&](int s, const float2 cur) {
             const int d = nd - 1 - s;
-            float right = wave_shift_down(b_prev, NEG);
+            float right = wave_shift_down(down, NEG);  // beta(t,u+1): lane u+1's value of the previous step
             if (NW > 1) {
                 const float edge = xch[1][(s + 1) & 1][w < NW - 1 ? w + 1 : 0];  // written at step s-1
-                right = (lane == kWave - 1 && w < NW - 1 && s > 0) ? edge : right;
+                if (lane == kWave - 1 && w < NW - 1) right = edge;
             }
-            const int t = d - u;
-            const float down_term = (t < T - 1) ? b_prev + cur.x : NEG;  // beta(t+1,u) + lp_blank(t,u)
-            const float right_term = (u < U) ? right + cur.y : NEG;      // beta(t,u+1) + lp_label(t,u)
-            float v = log_add_exp(right_term, down_term);
-            v = (t == T - 1 && u == U) ? cur.x : v;
-            v = (col_ok && t >= 0 && t < T) ? v : NEG;
+            if (s == 0) right = NEG;  // the virtual 0 in lane U belongs to lane U alone
+            const float v = log_add_exp(right + cur.y, down + cur.x);
             out[(size_t)(d >= 0 ? d : junk) * US] = v;
-            b_prev = v;
+            down = v;
             if (NW > 1) {
                 if (lane == 0) xch[1][s & 1][w] = v;
                 __syncthreads();
@@ -466,16 +457,16 @@ __global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(Lattice L, flo
         };
         float2 ra[kPF], rb[kPF];
 #pragma unroll
-        for (int i = 0; i < kPF; ++i) ra[i] = lp[row_of(i)];
+        for (int i = 0; i < kPF; ++i) ra[i] = lpc[row_of(nd - 1 - i)];
         for (int s0 = 0; s0 < nsteps; s0 += 2 * kPF) {
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {
-                rb[i] = lp[row_of(s0 + kPF + i)];
+                rb[i] = lpc[row_of(nd - 1 - (s0 + kPF + i))];
                 step(s0 + i, ra[i]);
             }
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {
-                ra[i] = lp[row_of(s0 + 2 * kPF + i)];
+                ra[i] = lpc[row_of(nd - 1 - (s0 + 2 * kPF + i))];
                 step(s0 + kPF + i, rb[i]);
             }
         }
