@@ -193,6 +193,15 @@ def main():
     k1 = float(np.mean([e.elapsed_ms(0, 1) for e in fwd_ev]))
     k2 = float(np.mean([e.elapsed_ms(1, 2) for e in fwd_ev]))
     k3 = float(np.mean([e.elapsed_ms(0, 1) for e in bwd_ev]))
+
+    def span_ms(a, b):  # start of a step's K1 -> end of its K3, on the launch stream
+        import ctypes
+        ms = ctypes.c_float(0.0)
+        _lib.check(_lib.load().rnnt_event_elapsed_ms(a, b, ctypes.byref(ms)), "rnnt_event_elapsed_ms")
+        return float(ms.value)
+
+    per_step = [span_ms(f.handles[0], b.handles[1]) for f, b in zip(fwd_ev, bwd_ev)]
+    p10, p50, p90 = (float(x) for x in np.percentile(per_step, [10, 50, 90]))
     loss_val = float(loss.detach().cpu()[0])
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -244,6 +253,7 @@ def main():
             "avg_launch_ms": round(k3, 4),
         },
         "stages_ms": {"k1_lse": round(k1, 4), "k2_lattice_and_reduce": round(k2, 4), "k3_grad": round(k3, 4)},
+        "step_device_ms": {"p10": round(p10, 4), "median": round(p50, 4), "p90": round(p90, 4)},
         "k1_achieved_GBs": round(k1_bytes / (k1 * 1e-3) / 1e9, 1),
         "whole_step": {
             "algorithmic_bytes": step_bytes,

@@ -18,7 +18,7 @@ inside K3.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -44,6 +44,29 @@ def shard_batch(acts, labels, act_lens, label_lens, world_size: int, rank: int):
     """
     lo, hi = shard_bounds(acts.shape[0], world_size, rank)
     return acts[lo:hi], labels[lo:hi], act_lens[lo:hi], label_lens[lo:hi]
+
+
+def balanced_assignment(act_lens: Sequence[int], label_lens: Sequence[int], world_size: int) -> List[List[int]]:
+    """Utterance indices per rank for a RAGGED batch, balancing lattice work Σ T_b·(U_b+1).
+
+    Utterances are sorted by lattice size and dealt in serpentine order (0..g-1, g-1..0, ...), so
+    every rank gets ⌊B/g⌋ or ⌈B/g⌉ utterances and the per-rank byte counts (K1/K3 read T_b·(U_b+1)·V
+    logits per utterance) differ by at most one utterance's worth per pass.  Each rank's list is
+    returned in ascending index order.  Contiguous shards (``shard_bounds``) need no such step when
+    lengths are uniform (BASELINE config 4).  Pass a rank's list as ``index=`` to
+    :class:`ShardedRNNTLoss`.
+    """
+    if len(act_lens) != len(label_lens):
+        raise ValueError("need one (act_len, label_len) pair per utterance")
+    if world_size < 1 or len(act_lens) < world_size:
+        raise ValueError("need at least one utterance per rank")
+    work = [int(t) * (int(u) + 1) for t, u in zip(act_lens, label_lens)]
+    order = sorted(range(len(work)), key=lambda i: (-work[i], i))
+    parts: List[List[int]] = [[] for _ in range(world_size)]
+    for k, i in enumerate(order):
+        lap, pos = divmod(k, world_size)
+        parts[pos if lap % 2 == 0 else world_size - 1 - pos].append(i)
+    return [sorted(p) for p in parts]
 
 
 def _default_loss_fn(acts, labels, act_lens, label_lens, blank):
@@ -98,15 +121,30 @@ class ShardedRNNTLoss(torch.nn.Module):
         self.loss_fn = loss_fn or _default_loss_fn
 
     def forward(self, acts, labels, act_lens, label_lens, global_batch: Optional[int] = None,
-                offset: Optional[int] = None):
+                offset: Optional[int] = None, index: Optional[Sequence[int]] = None):
+        """``offset``: position of a contiguous shard in the global batch (default: ``shard_bounds``).
+        ``index``: global positions of the local utterances for a non-contiguous partition
+        (``balanced_assignment``); needs ``global_batch``."""
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("ShardedRNNTLoss needs an initialised torch.distributed process group")
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         b_local = acts.shape[0]
+        if index is not None:
+            if global_batch is None or offset is not None:
+                raise ValueError("index= needs global_batch= and excludes offset=")
+            where = torch.as_tensor(list(index), dtype=torch.long)
+            if where.numel() != b_local or len(set(where.tolist())) != b_local:
+                raise ValueError("index must name one distinct global position per local utterance")
+            if int(where.min()) < 0 or int(where.max()) >= global_batch:
+                raise ValueError("shard does not fit the global batch")
+        else:
+            where = None
         if global_batch is None:
             global_batch = b_local * world  # equal shards
-        if offset is None:
+        if where is not None:
+            offset = 0
+        elif offset is None:
             lo, hi = shard_bounds(global_batch, world, rank)
             if hi - lo != b_local:
                 raise ValueError(
@@ -122,12 +160,19 @@ class ShardedRNNTLoss(torch.nn.Module):
 
         # the one collective: per-utterance costs, 4*B_global bytes, latency-bound
         gathered = torch.zeros(global_batch, dtype=torch.float32, device=local.device)
-        gathered[offset:offset + b_local] = local.detach()
+        if where is not None:
+            where = where.to(local.device)
+            gathered[where] = local.detach()
+        else:
+            gathered[offset:offset + b_local] = local.detach()
         dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group)
 
         if self.reduction == "none":
             out = gathered.clone()
-            out[offset:offset + b_local] = local  # local slice carries the graph
+            if where is not None:
+                out[where] = local  # local entries carry the graph
+            else:
+                out[offset:offset + b_local] = local
             return out
         factor = 1.0 / global_batch if self.reduction == "mean" else 1.0
         value = ordered_reduce(gathered, self.reduction)

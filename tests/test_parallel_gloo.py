@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from rnnt_amd.parallel import ShardedRNNTLoss, ordered_reduce, shard_batch, shard_bounds  # noqa: E402
+from rnnt_amd.parallel import (ShardedRNNTLoss, balanced_assignment, ordered_reduce, shard_batch,  # noqa: E402
+                               shard_bounds)
 
 
 class OracleCosts(torch.autograd.Function):
@@ -95,6 +96,60 @@ def test_sharded_equals_unsharded_bitwise(tmp_path, world, B, reduction):
         np.testing.assert_array_equal(z["loss"], ref_loss)       # identical bits on every rank
         np.testing.assert_array_equal(z["grad"], ref_g[lo:hi])       # and identical gradient bits
         assert np.all((z["grad"] == 0) == (ref_g[lo:hi] == 0))   # padding stays exactly zero
+
+
+def balanced_worker(rank, world, port, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cases import make_case
+
+        acts, labels, al, ll = make_case(B, 9, 4, 12, seed=78, ragged=True, sigma=2.0)
+        mine = balanced_assignment(al, ll, world)[rank]
+        a = torch.from_numpy(acts[mine]).requires_grad_(True)
+        crit = ShardedRNNTLoss(blank=0, reduction="mean", loss_fn=oracle_loss_fn)
+        loss = crit(a, torch.from_numpy(labels[mine]), torch.from_numpy(al[mine]), torch.from_numpy(ll[mine]),
+                    global_batch=B, index=mine)
+        loss.backward(torch.tensor([0.5]))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=loss.detach().numpy(), grad=a.grad.numpy(),
+                 index=np.asarray(mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balanced_partition_equals_unsharded_bitwise(tmp_path):
+    import oracle
+    from cases import make_case
+
+    world, B = 2, 7
+    mp.spawn(balanced_worker, args=(world, free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    acts, labels, al, ll = make_case(B, 9, 4, 12, seed=78, ragged=True, sigma=2.0)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll, num_threads=1)
+    ref_loss = ordered_reduce(torch.from_numpy(c), "mean").numpy()
+    ref_g = g * (np.float32(0.5) * np.float32(1.0 / B))
+    seen = []
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        np.testing.assert_array_equal(z["loss"], ref_loss)
+        np.testing.assert_array_equal(z["grad"], ref_g[z["index"]])
+        seen += z["index"].tolist()
+    assert sorted(seen) == list(range(B))
+
+
+def test_balanced_assignment_balances_lattice_work():
+    rng = np.random.default_rng(5)
+    al = rng.integers(100, 801, size=64)
+    ll = rng.integers(10, 61, size=64)
+    parts = balanced_assignment(al, ll, 8)
+    assert sorted(i for p in parts for i in p) == list(range(64))
+    assert all(len(p) == 8 for p in parts)
+    work = np.array([sum(int(al[i]) * (int(ll[i]) + 1) for i in p) for p in parts], float)
+    contiguous = np.array([sum(int(al[i]) * (int(ll[i]) + 1) for i in range(8 * r, 8 * r + 8)) for r in range(8)], float)
+    assert work.max() / work.mean() < 1.05 < contiguous.max() / contiguous.mean()
+    assert [len(p) for p in balanced_assignment([5, 4, 3, 2, 1], [0] * 5, 2)] == [3, 2]
+    with pytest.raises(ValueError):
+        balanced_assignment([1], [1], 2)
 
 
 def test_shard_bounds():
