@@ -16,8 +16,10 @@ Three independent statements of the loss the reference obtains from
 
 PARITY UNPINNED: the reference has no tests or golden vectors for this path and
 the upstream package cannot be built or imported here.  The
-three statements are checked against each other and against the upstream
-B1·T2·U2·V5 known-answer vector in ``tests/test_oracle.py``.
+three statements are checked against each other and against two known-answer
+vectors of the upstream package's own unit tests (B1·T2·U2·V5 and the
+two-utterance B2·T4·U2·V3 case, both recalled; ``tests/cases.py``) in
+``tests/test_oracle.py``.
 """
 from __future__ import annotations
 

@@ -6,7 +6,7 @@ package it imports (warprnnt_pytorch) is neither vendored nor importable here, s
 come from the build's own float64 restatement (oracle/rnnt_oracle.c, fp64 instantiation), which
 tests/test_oracle.py cross-checks against autograd through a float64 DP and against brute-force
 path enumeration.  PARITY UNPINNED with respect to the real warp-transducer; the one upstream
-anchor is KAT-1 (kat1.npz), recalled from the upstream package's public unit test.
+anchors are KAT-1 and KAT-2 (kat1.npz, kat2.npz), recalled from the upstream package's public unit test.
 
 Each file: acts f32 [B,T,U+1,V], labels i32 [B,U], act_lens i32 [B], label_lens i32 [B],
 costs f64 [B] (-log P per utterance), grads f64 [B,T,U+1,V] (d costs[b] / d acts[b]).
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle  # noqa: E402
-from cases import KAT1, make_case  # noqa: E402
+from cases import KAT1, KAT2, make_case  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -50,6 +50,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "kat1.npz"), acts=KAT1["acts64"], labels=KAT1["labels"],
                         act_lens=KAT1["act_lens"], label_lens=KAT1["label_lens"],
                         costs=np.array([KAT1["cost"]]), grads=KAT1["grads"], blank=np.int32(0))
+    # KAT-2: inputs and costs are upstream's; the full gradient is the float64 oracle's (only its
+    # first node is recalled from upstream, asserted in tests/test_oracle.py)
+    c2, g2, _ = oracle.rnnt_loss_c(KAT2["acts64"], KAT2["labels"], KAT2["act_lens"], KAT2["label_lens"],
+                                   dtype=np.float64)
+    assert np.abs(c2 - KAT2["costs"]).max() < 1e-12
+    np.savez_compressed(os.path.join(OUT, "kat2.npz"), acts=KAT2["acts64"], labels=KAT2["labels"],
+                        act_lens=KAT2["act_lens"], label_lens=KAT2["label_lens"],
+                        costs=KAT2["costs"], grads=g2, blank=np.int32(0))
 
 
 if __name__ == "__main__":

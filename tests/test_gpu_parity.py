@@ -9,7 +9,10 @@ import pytest
 import torch
 
 import oracle
-from cases import KAT1, make_case
+import glob
+import os
+
+from cases import KAT1, KAT2, make_case
 
 pytestmark = pytest.mark.gpu
 
@@ -48,6 +51,30 @@ def test_kat1_upstream_vector():
     assert loss.shape == (1,)
     np.testing.assert_allclose(loss[0], KAT1["cost"], rtol=LOSS_RTOL)
     assert np.abs(grads - KAT1["grads"]).max() <= 1e-6
+
+
+def test_kat2_upstream_two_utterance_vector():
+    """reduction='none' shows both of upstream's expected costs; 'mean' is RNNTLoss()'s default."""
+    args = (KAT2["acts"], KAT2["labels"], KAT2["act_lens"], KAT2["label_lens"])
+    costs, grads = run_gpu(*args, reduction="none")
+    np.testing.assert_allclose(costs, KAT2["costs"], rtol=LOSS_RTOL)
+    assert np.abs(grads[0, 0] - KAT2["grads_b0_t0"]).max() <= 1e-6
+    loss, grads_mean = run_gpu(*args)
+    np.testing.assert_allclose(loss[0], KAT2["costs"].mean(), rtol=LOSS_RTOL)
+    assert np.abs(grads_mean - grads / 2).max() <= 1e-7
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_committed_golden_fixtures(path):
+    """The fixtures hold float64 answers (tests/golden/make_golden.py); the GPU gets the fp32 logits."""
+    z = np.load(path)  # allow_pickle=False (default)
+    costs, grads = run_gpu(z["acts"].astype(np.float32), z["labels"], z["act_lens"], z["label_lens"],
+                           reduction="none", blank=int(z["blank"]))
+    np.testing.assert_allclose(costs, z["costs"], rtol=LOSS_RTOL)
+    assert np.abs(grads - z["grads"]).max() <= GRAD_ATOL
 
 
 @pytest.mark.parametrize("B,T,U,V,seed", [

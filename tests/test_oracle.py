@@ -1,7 +1,7 @@
 """CPU tests of the oracle itself (no GPU): the three independent statements of the loss agree,
 the upstream known-answer vector reproduces, the golden fixtures are stable, and the domain
 properties SURVEY.md §4 lists hold.  PARITY UNPINNED w.r.t. the real warp-transducer (no reference
-fixtures exist); KAT-1 is the one upstream anchor."""
+fixtures exist); KAT-1 and KAT-2 (upstream's public unit-test vectors, recalled) are the anchors."""
 import glob
 import os
 
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from cases import KAT1, make_case
+from cases import KAT1, KAT2, make_case
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
@@ -29,6 +29,25 @@ def test_kat1_all_statements():
     assert np.abs(g64 - KAT1["grads"]).max() < 1e-8
     assert np.abs(gdp - KAT1["grads"]).max() < 1e-8
     assert np.abs(g32 - KAT1["grads"]).max() < 1e-6
+
+
+def test_kat2_two_utterances_all_statements():
+    lab, al, ll = KAT2["labels"], KAT2["act_lens"], KAT2["label_lens"]
+    a64 = KAT2["acts64"]
+    c64, g64, _ = oracle.rnnt_loss_c(a64, lab, al, ll, dtype=np.float64)
+    cdp, gdp = oracle.rnnt_loss_dp_f64(a64, lab, al, ll)
+    cbf = oracle.rnnt_loss_bruteforce(a64, lab, al, ll)
+    for c in (c64, cdp, cbf):
+        assert np.abs(np.asarray(c) - KAT2["costs"]).max() < 1e-12   # upstream's 17-digit expected costs
+    assert np.abs(g64 - gdp).max() < 1e-12
+    # upstream's expected gradient (recalled part) was produced in float32: it sits 3e-9..7e-8 from float64
+    assert np.abs(g64[0, 0] - KAT2["grads_b0_t0"]).max() < 2e-7
+    c32, g32, _ = oracle.rnnt_loss_c(KAT2["acts"], lab, al, ll)
+    np.testing.assert_allclose(c32, KAT2["costs"], rtol=1e-6)
+    assert np.abs(g32 - g64).max() < 1e-6
+    # 'mean' as the reference's RNNTLoss() default: (c0 + c1) / 2
+    loss, _ = oracle.reduce_like_upstream(c32, g32, "mean", 1.0)
+    assert abs(loss[0] - KAT2["costs"].mean()) < 1e-6
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -73,7 +92,7 @@ def test_golden_fixtures(path):
 
 def test_golden_set_is_complete():
     names = {os.path.basename(p) for p in GOLDEN}
-    assert {"kat1.npz", "tiny_T1_U0.npz", "ragged_small.npz", "wide_lattice_U70.npz"} <= names
+    assert {"kat1.npz", "kat2.npz", "tiny_T1_U0.npz", "ragged_small.npz", "wide_lattice_U70.npz"} <= names
 
 
 # ---- properties -------------------------------------------------------------------
