@@ -122,6 +122,33 @@ rnntStatus_t compute_rnnt_loss(const void *acts, void *grads, const int *labels,
 rnntStatus_t rnnt_reduce_costs(const float *costs, float *loss_out, int minibatch, int reduction,
                                void *stream);
 
+/*
+ * ---- next to the loss: the hidden layer of the joint network -----------------
+ *
+ * Replaces the repeat / cat / Linear(He+Hd -> H) / Tanh of the reference's JointNet.forward
+ * (/root/reference/src/rnnt/model.py:46-54 with the mlp of :14-16).  Linear(cat(e,d)) = W_e e + W_d d + b,
+ * so the caller runs two small GEMMs (enc_proj = enc W_e^T + b: [B,T,H]; dec_proj = dec W_d^T: [B,U1,H])
+ * and this entry point produces what the reference's Tanh returns:
+ *     hidden[b,t,u,:] = tanh(enc_proj[b,t,:] + dec_proj[b,u,:])        [B,T,U1,H], contiguous
+ * joint="sum" (model.py:43-44) is the same kernel with W_e = W_d.  All three arrays have element type
+ * `dtype`; arithmetic is fp32.  U1 = U+1 (the decoder saw BOS + U labels, model.py:106,114).
+ */
+rnntStatus_t rnnt_joint_hidden_forward(const void *enc_proj, const void *dec_proj, void *hidden, int B, int T,
+                                       int U1, int H, rnntDtype_t dtype, void *stream);
+
+/* Bytes of fp32 scratch rnnt_joint_hidden_backward needs (partial sums over frame chunks). */
+rnntStatus_t rnnt_joint_hidden_workspace_size(int B, int T, int U1, int H, size_t *size_bytes);
+
+/*
+ * Backward of the above (what autograd runs through Tanh, Linear, cat and the two repeats in the
+ * reference):  g = grad_hidden * (1 - hidden^2);  grad_enc_proj[b,t,:] = sum_u g;
+ * grad_dec_proj[b,u,:] = sum_t g.  Sums are formed in a fixed order (no atomics): results are bitwise
+ * reproducible.  The library allocates nothing; `workspace` comes from the caller.
+ */
+rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hidden, void *grad_enc_proj,
+                                        void *grad_dec_proj, int B, int T, int U1, int H, rnntDtype_t dtype,
+                                        void *workspace, void *stream);
+
 /* hipEvent helpers so a ctypes caller (bench.py) can time stages without a HIP binding. */
 rnntStatus_t rnnt_event_create(void **event);
 rnntStatus_t rnnt_event_destroy(void *event);

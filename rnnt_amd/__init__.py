@@ -2,12 +2,14 @@
 
 Scope: the one hot path the reference reaches at /root/reference/src/rnnt/model.py:116 plus the
 batch-sharding harness that replaces its ``DataParallel`` use (bin/train.py:241-244).
+``JointNet`` / ``joint_hidden`` are the first widening next to that path.
 See DESIGN.md.  Importing this package does not load the HIP library; the first loss call does,
 and raises if ``rnnt_amd/lib/librnnt_mi355.so`` is missing (no fallback exists).
 """
 from .loss import RNNTLoss, rnnt_loss, certify_inputs  # noqa: F401
+from .joint import JointNet, joint_hidden  # noqa: F401
 from .parallel import ShardedRNNTLoss, balanced_assignment, shard_bounds, shard_batch  # noqa: F401
 
 __all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch",
-           "balanced_assignment"]
+           "balanced_assignment", "JointNet", "joint_hidden"]
 __version__ = "0.1.0"

@@ -32,6 +32,9 @@ EXPORTED_SYMBOLS = (
     "rnnt_backward",
     "compute_rnnt_loss",
     "rnnt_reduce_costs",
+    "rnnt_joint_hidden_forward",
+    "rnnt_joint_hidden_workspace_size",
+    "rnnt_joint_hidden_backward",
     "rnnt_event_create",
     "rnnt_event_destroy",
     "rnnt_event_record",
@@ -105,6 +108,15 @@ def load() -> ctypes.CDLL:
         lib.compute_rnnt_loss.restype = ctypes.c_int
         lib.rnnt_reduce_costs.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_reduce_costs.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.rnnt_joint_hidden_forward.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_workspace_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.POINTER(ctypes.c_size_t)]
+        lib.rnnt_joint_hidden_workspace_size.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_backward.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
+        lib.rnnt_joint_hidden_backward.restype = ctypes.c_int
         lib.rnnt_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         lib.rnnt_event_create.restype = ctypes.c_int
         lib.rnnt_event_destroy.argtypes = [ctypes.c_void_p]

@@ -1,0 +1,365 @@
+// joint_mi355.hip — the hidden layer of the transducer's joint network on MI355X (gfx950).
+//
+// The reference's JointNet.forward (/root/reference/src/rnnt/model.py:39-59) repeats the encoder
+// state over U+1 and the decoder state over T, concatenates them to [B,T,U+1,He+Hd], and runs
+// Linear(He+Hd -> H) + Tanh over all B*T*(U+1) rows.  Linear(cat(e,d)) = W_e e + W_d d + bias, so
+// the layer is two small GEMMs (done by the caller: [B*T,He]x[He,H] and [B*(U+1),Hd]x[Hd,H]) and
+//     hidden[b,t,u,:] = tanh(enc_proj[b,t,:] + dec_proj[b,u,:])
+// which is what these kernels compute, with its backward.  SURVEY.md §8f rank 2.  Both kernels
+// are HBM-bound streams: forward writes B*T*(U+1)*H elements once, backward reads hidden and its
+// gradient once.  Nothing of size [.., He+Hd] is ever materialised.
+//
+// Backward:  g = grad_hidden * (1 - hidden^2);  grad_enc_proj[b,t,:] = sum_u g;
+//            grad_dec_proj[b,u,:] = sum_t g.
+// The sum over t crosses waves: each wave owns a 16-frame chunk of one utterance and a slice of
+// columns, reduces its frames in registers (no LDS, no barrier) and writes one fp32 partial row
+// piece per (b, frame-chunk, u); a second small kernel adds the partials in chunk order.  No
+// atomics, so results are bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/rnnt_mi355.h"
+#include "elem_types.h"
+
+namespace {
+
+using namespace rnnt_mi355_detail;
+
+constexpr int kJW = 4;    // waves per workgroup, forward
+constexpr int kJCH = 2;   // 16-byte (or scalar) pieces per lane per row tile
+constexpr int kBW = 4;    // waves per workgroup, backward (independent of each other)
+constexpr int kTC = 16;   // frames per wave in the backward kernel
+
+// A lane's piece of a row: VEC elements (VEC = DT::EPC through 16-byte accesses, or 1)
+template <typename DT, int VEC>
+struct Piece {
+    float x[VEC];
+    __device__ __forceinline__ void load(const typename DT::elem *p) {
+        if constexpr (VEC == 1) {
+            x[0] = DT::to_float(*p);
+        } else {
+            const u32x4 raw = *reinterpret_cast<const u32x4 *>(p);
+            DT::unpack(raw, x);
+        }
+    }
+    __device__ __forceinline__ void load_nt(const typename DT::elem *p) {
+        if constexpr (VEC == 1) {
+            x[0] = DT::to_float(__builtin_nontemporal_load(p));
+        } else {
+            const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+            DT::unpack(raw, x);
+        }
+    }
+    __device__ __forceinline__ void store_nt(typename DT::elem *p) const {
+        if constexpr (VEC == 1) {
+            __builtin_nontemporal_store(DT::from_float(x[0]), p);
+        } else {
+            __builtin_nontemporal_store(DT::pack(x), reinterpret_cast<u32x4 *>(p));
+        }
+    }
+    __device__ __forceinline__ void store(typename DT::elem *p) const {
+        if constexpr (VEC == 1) {
+            *p = DT::from_float(x[0]);
+        } else {
+            *reinterpret_cast<u32x4 *>(p) = DT::pack(x);
+        }
+    }
+};
+
+// backward pieces: 4 elements per lane (16 bytes of fp32, 8 bytes of a 16-bit type) or 1
+template <typename DT, int VEC>
+__device__ __forceinline__ void load4_nt(const typename DT::elem *p, float (&x)[VEC]) {
+    if constexpr (VEC == 1) {
+        x[0] = DT::to_float(__builtin_nontemporal_load(p));
+    } else if constexpr (sizeof(typename DT::elem) == 4) {
+        const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        x[0] = __uint_as_float(raw.x);
+        x[1] = __uint_as_float(raw.y);
+        x[2] = __uint_as_float(raw.z);
+        x[3] = __uint_as_float(raw.w);
+    } else {
+        typedef typename DT::elem e4 __attribute__((ext_vector_type(4)));
+        const e4 raw = __builtin_nontemporal_load(reinterpret_cast<const e4 *>(p));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = DT::to_float(raw[j]);
+    }
+}
+template <typename DT, int VEC>
+__device__ __forceinline__ void store4(typename DT::elem *p, const float (&x)[VEC]) {
+    if constexpr (VEC == 1) {
+        *p = DT::from_float(x[0]);
+    } else {
+        typedef typename DT::elem e4 __attribute__((ext_vector_type(4)));
+        e4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = DT::from_float(x[j]);
+        *reinterpret_cast<e4 *>(p) = v;
+    }
+}
+
+// tanh for the forward pass.  fp32 outputs use the device libm (about 1 ulp, as torch's tanh).  16-bit
+// outputs are rounded to 2^-9 / 2^-12 relative anyway, so they take (1-t)/(1+t), t = e^(-2|x|), whose
+// absolute error is ~1e-7: two transcendental instructions instead of libm's ~25 VALU slots, which is
+// what bounds the 16-bit kernel.
+template <typename DT>
+__device__ __forceinline__ float joint_tanh(float x) {
+    if constexpr (sizeof(typename DT::elem) == 4) {
+        return tanhf(x);
+    } else {
+        const float t = __builtin_amdgcn_exp2f(-2.f * 1.4426950408889634f * fabsf(x));
+        const float r = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+        return copysignf(r, x);  // NaN in, NaN out; +-inf -> +-1
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: one wave per (b,t); the enc_proj piece stays in registers while u runs over U1
+// grid = (ceil(B*T / kJW), ceil(H / CW)),  CW = 64 * VEC * kJCH columns per tile
+// ---------------------------------------------------------------------------------------------
+template <typename DT, int VEC>
+__global__ __launch_bounds__(kJW *kWave) void joint_hidden_fwd(const typename DT::elem *__restrict__ enc_proj,
+                                                                const typename DT::elem *__restrict__ dec_proj,
+                                                                typename DT::elem *__restrict__ hidden,
+                                                                long long BT, int T, int U1, int H) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const long long p = (long long)blockIdx.x * kJW + wave;  // = b*T + t
+    if (p >= BT) return;
+    const int b = (int)(p / T);
+    const int col0 = blockIdx.y * (kWave * VEC * kJCH) + lane * VEC;
+
+    Piece<DT, VEC> e[kJCH];
+    bool ok[kJCH];
+#pragma unroll
+    for (int k = 0; k < kJCH; ++k) {
+        const int c = col0 + k * kWave * VEC;
+        ok[k] = c < H;
+        if (ok[k]) {
+            e[k].load(enc_proj + (size_t)p * H + c);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) e[k].x[j] = 0.f;
+        }
+    }
+    const typename DT::elem *drow = dec_proj + (size_t)b * U1 * H;
+    typename DT::elem *hrow = hidden + (size_t)p * U1 * H;
+#pragma unroll 4
+    for (int u = 0; u < U1; ++u) {
+#pragma unroll
+        for (int k = 0; k < kJCH; ++k) {
+            if (!ok[k]) continue;
+            const int c = col0 + k * kWave * VEC;
+            Piece<DT, VEC> d, y;
+            d.load(drow + (size_t)u * H + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) y.x[j] = joint_tanh<DT>(e[k].x[j] + d.x[j]);
+            y.store_nt(hrow + (size_t)u * H + c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: one wave per (b, 16-frame chunk, column slice of 64*VEC); waves are independent
+// ---------------------------------------------------------------------------------------------
+template <typename DT, int VEC>
+__global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT::elem *__restrict__ hidden,
+                                                                const typename DT::elem *__restrict__ grad_hidden,
+                                                                typename DT::elem *__restrict__ grad_enc_proj,
+                                                                float *__restrict__ partial, long long items, int T,
+                                                                int U1, int H, int nchunk, int nslice) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long w = (long long)blockIdx.x * kBW + threadIdx.x / kWave;
+    if (w >= items) return;
+    const int slice = (int)(w % nslice);
+    const long long bc = w / nslice;
+    const int chunk = (int)(bc % nchunk);
+    const int b = (int)(bc / nchunk);
+    const int col = slice * kWave * VEC + lane * VEC;
+    const bool ok = col < H;
+    const int colc = ok ? col : H - VEC;  // surplus lanes read a valid piece and store nothing
+    const int t0 = chunk * kTC;
+    const int nt = T - t0 < kTC ? T - t0 : kTC;  // wave-uniform
+
+    float acc_e[kTC][VEC];
+#pragma unroll
+    for (int i = 0; i < kTC; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc_e[i][j] = 0.f;
+
+    const size_t frame_stride = (size_t)U1 * H;
+    const typename DT::elem *hp = hidden + ((size_t)b * T + t0) * frame_stride + colc;
+    const typename DT::elem *gp = grad_hidden + ((size_t)b * T + t0) * frame_stride + colc;
+    float *pp = partial + ((size_t)b * nchunk + chunk) * frame_stride + col;
+
+    if (nt == kTC) {  // every chunk but the last: unconditional loads, fully unrolled
+        for (int u = 0; u < U1; ++u) {
+            float acc_d[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc_d[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < kTC; ++i) {
+                float hx[VEC], gx[VEC];
+                load4_nt<DT, VEC>(hp + i * frame_stride + (size_t)u * H, hx);
+                load4_nt<DT, VEC>(gp + i * frame_stride + (size_t)u * H, gx);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float v = gx[j] * (1.f - hx[j] * hx[j]);
+                    acc_d[j] += v;
+                    acc_e[i][j] += v;
+                }
+            }
+            if (ok) store4<F32, VEC>(pp + (size_t)u * H, acc_d);
+        }
+    } else {
+        for (int u = 0; u < U1; ++u) {
+            float acc_d[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc_d[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < kTC; ++i) {
+                if (i < nt) {
+                    float hx[VEC], gx[VEC];
+                    load4_nt<DT, VEC>(hp + i * frame_stride + (size_t)u * H, hx);
+                    load4_nt<DT, VEC>(gp + i * frame_stride + (size_t)u * H, gx);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float v = gx[j] * (1.f - hx[j] * hx[j]);
+                        acc_d[j] += v;
+                        acc_e[i][j] += v;
+                    }
+                }
+            }
+            if (ok) store4<F32, VEC>(pp + (size_t)u * H, acc_d);
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < kTC; ++i)
+            if (i < nt) store4<DT, VEC>(grad_enc_proj + ((size_t)b * T + t0 + i) * H + col, acc_e[i]);
+    }
+}
+
+// grad_dec_proj[b,u,:] = sum over frame chunks, in chunk order
+template <typename DT>
+__global__ __launch_bounds__(256) void joint_dec_reduce(const float *__restrict__ partial,
+                                                        typename DT::elem *__restrict__ grad_dec_proj, int B,
+                                                        int U1, int H, int nchunk) {
+    const size_t per_b = (size_t)U1 * H;
+    const size_t total = (size_t)B * per_b;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_b, r = i - b * per_b;
+        const float *p = partial + b * nchunk * per_b + r;
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += p[(size_t)c * per_b];
+        grad_dec_proj[i] = DT::from_float(s);
+    }
+}
+
+inline int frame_chunks(int T) { return (T + kTC - 1) / kTC; }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline bool shape_ok(int B, int T, int U1, int H) {
+    // grid.y / grid.z limits and int row arithmetic
+    return B >= 1 && T >= 1 && U1 >= 1 && H >= 1 && B <= 65535 && (long long)B * T < (1ll << 40) &&
+           (long long)U1 * H < (1ll << 31);
+}
+
+template <typename DT>
+rnntStatus_t launch_fwd(const void *enc_proj, const void *dec_proj, void *hidden, int B, int T, int U1, int H,
+                        hipStream_t st) {
+    typedef typename DT::elem E;
+    const bool vec = H % DT::EPC == 0 && aligned16(enc_proj) && aligned16(dec_proj) && aligned16(hidden);
+    const long long BT = (long long)B * T;
+    const long long gx = (BT + kJW - 1) / kJW;
+    if (gx > 0x7fffffffll) return RNNT_STATUS_INVALID_VALUE;
+    if (vec) {
+        const int cw = kWave * DT::EPC * kJCH;
+        hipLaunchKernelGGL((joint_hidden_fwd<DT, DT::EPC>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0,
+                           st, static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
+                           static_cast<E *>(hidden), BT, T, U1, H);
+    } else {
+        const int cw = kWave * kJCH;
+        hipLaunchKernelGGL((joint_hidden_fwd<DT, 1>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0, st,
+                           static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
+                           static_cast<E *>(hidden), BT, T, U1, H);
+    }
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
+
+inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+template <typename DT>
+rnntStatus_t launch_bwd(const void *hidden, const void *grad_hidden, void *grad_enc_proj, void *grad_dec_proj,
+                        int B, int T, int U1, int H, void *workspace, hipStream_t st) {
+    typedef typename DT::elem E;
+    const size_t piece = 4 * sizeof(E);
+    const bool vec = H % 4 == 0 && aligned_to(hidden, piece) && aligned_to(grad_hidden, piece) &&
+                     aligned_to(grad_enc_proj, piece);
+    const int nchunk = frame_chunks(T);
+    float *partial = static_cast<float *>(workspace);
+    const int width = kWave * (vec ? 4 : 1);
+    const int nslice = (H + width - 1) / width;
+    const long long items = (long long)B * nchunk * nslice;
+    const long long gx = (items + kBW - 1) / kBW;
+    if (gx > 0x7fffffffll) return RNNT_STATUS_INVALID_VALUE;
+    if (vec) {
+        hipLaunchKernelGGL((joint_hidden_bwd<DT, 4>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
+                           static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice);
+    } else {
+        hipLaunchKernelGGL((joint_hidden_bwd<DT, 1>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
+                           static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice);
+    }
+    if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    const size_t total = (size_t)B * U1 * H;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL((joint_dec_reduce<DT>), dim3(blocks), dim3(256), 0, st, partial,
+                       static_cast<E *>(grad_dec_proj), B, U1, H, nchunk);
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
+
+}  // namespace
+
+extern "C" {
+
+rnntStatus_t rnnt_joint_hidden_workspace_size(int B, int T, int U1, int H, size_t *size_bytes) {
+    if (size_bytes == nullptr || !shape_ok(B, T, U1, H)) return RNNT_STATUS_INVALID_VALUE;
+    *size_bytes = (size_t)B * frame_chunks(T) * U1 * H * sizeof(float);
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t rnnt_joint_hidden_forward(const void *enc_proj, const void *dec_proj, void *hidden, int B, int T,
+                                       int U1, int H, rnntDtype_t dtype, void *stream) {
+    if (enc_proj == nullptr || dec_proj == nullptr || hidden == nullptr || !shape_ok(B, T, U1, H))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32: return launch_fwd<F32>(enc_proj, dec_proj, hidden, B, T, U1, H, st);
+        case RNNT_DTYPE_BF16: return launch_fwd<BF16>(enc_proj, dec_proj, hidden, B, T, U1, H, st);
+        case RNNT_DTYPE_F16: return launch_fwd<F16>(enc_proj, dec_proj, hidden, B, T, U1, H, st);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hidden, void *grad_enc_proj,
+                                        void *grad_dec_proj, int B, int T, int U1, int H, rnntDtype_t dtype,
+                                        void *workspace, void *stream) {
+    if (hidden == nullptr || grad_hidden == nullptr || grad_enc_proj == nullptr || grad_dec_proj == nullptr ||
+        workspace == nullptr || !shape_ok(B, T, U1, H) || !aligned16(workspace))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32:
+            return launch_bwd<F32>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
+        case RNNT_DTYPE_BF16:
+            return launch_bwd<BF16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
+        case RNNT_DTYPE_F16:
+            return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+}  // extern "C"

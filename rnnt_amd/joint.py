@@ -1,0 +1,135 @@
+"""``JointNet`` with its hidden layer computed the MI355X way.
+
+Mirror of the reference's ``JointNet`` (/root/reference/src/rnnt/model.py:9-63): same constructor
+arguments, same parameter names (``mlp.0.weight`` ``[inner, input]``, ``mlp.0.bias``,
+``mlp.2.weight`` ``[vocab, inner]``, ``mlp.2.bias``) so a reference checkpoint loads with
+``load_state_dict``, same ``forward(enc_state, dec_state, softmax=False)`` returning the raw logits
+``[B, T, U+1, V]`` the loss takes (model.py:115-116).
+
+What changes is how the training path (3-D inputs) gets there.  The reference repeats both states
+to ``[B,T,U+1,·]``, concatenates them (model.py:49-54) and runs ``Linear(He+Hd -> H)`` and ``Tanh``
+over all B·T·(U+1) rows.  Here ``Linear(cat(e, d)) = W_e e + W_d d + b`` is evaluated as two small
+GEMMs on ``[B,T,He]`` and ``[B,U+1,Hd]`` and one HIP kernel forms
+``tanh(enc_proj[b,t] + dec_proj[b,u])`` (``rnnt_joint_hidden_forward``); backward is one streaming
+kernel plus a small ordered reduction (``rnnt_joint_hidden_backward``).  The output projection
+``Linear(H -> V)`` stays a plain library GEMM.  No CPU path for the 3-D case: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+
+
+def _workspace_bytes(B, T, U1, H) -> int:
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.load().rnnt_joint_hidden_workspace_size(B, T, U1, H, ctypes.byref(n)),
+               "rnnt_joint_hidden_workspace_size")
+    return int(n.value)
+
+
+class _JointHidden(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_proj, dec_proj):
+        B, T, H = enc_proj.shape
+        U1 = dec_proj.shape[1]
+        dev = enc_proj.device
+        enc_proj = enc_proj.contiguous()
+        dec_proj = dec_proj.contiguous()
+        with torch.cuda.device(dev):
+            hidden = torch.empty((B, T, U1, H), dtype=enc_proj.dtype, device=dev)
+            _lib.check(_lib.load().rnnt_joint_hidden_forward(
+                enc_proj.data_ptr(), dec_proj.data_ptr(), hidden.data_ptr(), B, T, U1, H,
+                _DTYPES[enc_proj.dtype], torch.cuda.current_stream(dev).cuda_stream), "rnnt_joint_hidden_forward")
+        ctx.save_for_backward(hidden)
+        return hidden
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_hidden):
+        (hidden,) = ctx.saved_tensors
+        B, T, U1, H = hidden.shape
+        dev = hidden.device
+        grad_hidden = grad_hidden.to(hidden.dtype).contiguous()
+        with torch.cuda.device(dev):
+            grad_enc = torch.empty((B, T, H), dtype=hidden.dtype, device=dev)
+            grad_dec = torch.empty((B, U1, H), dtype=hidden.dtype, device=dev)
+            ws = torch.empty(_workspace_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.load().rnnt_joint_hidden_backward(
+                hidden.data_ptr(), grad_hidden.data_ptr(), grad_enc.data_ptr(), grad_dec.data_ptr(), B, T, U1, H,
+                _DTYPES[hidden.dtype], ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                "rnnt_joint_hidden_backward")
+        return grad_enc, grad_dec
+
+
+def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor) -> torch.Tensor:
+    """``tanh(enc_proj[:, :, None, :] + dec_proj[:, None, :, :])`` → ``[B, T, U+1, H]`` on the MI355X.
+
+    ``enc_proj`` ``[B, T, H]``, ``dec_proj`` ``[B, U+1, H]``, same dtype (fp32, bf16 or fp16) and device.
+    """
+    if enc_proj.dim() != 3 or dec_proj.dim() != 3:
+        raise ValueError("enc_proj must be [B,T,H] and dec_proj [B,U+1,H]")
+    if enc_proj.shape[0] != dec_proj.shape[0] or enc_proj.shape[2] != dec_proj.shape[2]:
+        raise ValueError("enc_proj and dec_proj must agree in batch and hidden size")
+    if enc_proj.dtype not in _DTYPES or dec_proj.dtype is not enc_proj.dtype:
+        raise TypeError("enc_proj and dec_proj must both be torch.float32, torch.bfloat16 or torch.float16")
+    if min(enc_proj.shape) < 1 or min(dec_proj.shape) < 1:
+        raise ValueError("enc_proj and dec_proj must not be empty")
+    if not enc_proj.is_cuda or dec_proj.device != enc_proj.device:
+        raise RuntimeError("rnnt_amd.joint_hidden computes on MI355X (ROCm device tensors) only; there is no CPU "
+                           "path or PyTorch fallback in this package")
+    return _JointHidden.apply(enc_proj, dec_proj)
+
+
+class JointNet(nn.Module):
+    """Drop-in for the reference's ``JointNet`` (model.py:9-63); see the module docstring."""
+
+    def __init__(self, input_size, inner_dim, vocab_size, joint="concat"):
+        super().__init__()
+        self.joint = joint
+        self.mlp = nn.Sequential(
+            nn.Linear(input_size, inner_dim, bias=True),
+            nn.Tanh(),
+            nn.Linear(inner_dim, vocab_size, bias=True),
+        )
+
+    def forward(self, enc_state, dec_state, softmax=False):
+        if enc_state.dim() != dec_state.dim():
+            raise ValueError("input_TN and input_PN must be have same size."
+                             "3 for training, or 1,2 for evaluation")
+        if self.joint not in ("sum", "concat"):
+            raise NotImplementedError
+        if enc_state.dim() == 4 and enc_state.size(2) == 1 and dec_state.size(1) == 1:
+            # already unsqueezed by the caller ([B,T,1,He] / [B,1,U+1,Hd]), model.py:46-50
+            enc_state, dec_state = enc_state.squeeze(2), dec_state.squeeze(1)
+        if enc_state.dim() == 3:
+            first, out = self.mlp[0], self.mlp[2]
+            if self.joint == "concat":
+                he = enc_state.size(-1)
+                if he + dec_state.size(-1) != first.in_features:
+                    raise RuntimeError("enc/dec state sizes do not add up to the joint's input_size")
+                w_enc, w_dec = first.weight[:, :he], first.weight[:, he:]
+            else:
+                w_enc = w_dec = first.weight
+            enc_proj = F.linear(enc_state, w_enc, first.bias)      # [B, T, H]
+            dec_proj = F.linear(dec_state, w_dec)                  # [B, U+1, H]
+            joint = out(joint_hidden(enc_proj, dec_proj))          # [B, T, U+1, V]
+        else:
+            # evaluation: one frame against one decoder state ([B *] H), model.py:51-54 — a few hundred
+            # numbers; greedy/beam decoding is outside this package's scope
+            if self.joint == "sum":
+                concat_state = enc_state + dec_state
+            else:
+                concat_state = torch.cat((enc_state, dec_state), dim=-1)
+            joint = self.mlp(concat_state)
+        if softmax:
+            # the reference calls self.softmax here, an attribute its JointNet never defines
+            # (model.py:60-61): the call site raises AttributeError there, and so it does here
+            joint = self.softmax(joint)
+        return joint

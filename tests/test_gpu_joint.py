@@ -1,0 +1,177 @@
+"""GPU parity for the joint-network widening: rnnt_amd.joint_hidden / JointNet
+through the C ABI against the CPU restatement of the reference's JointNet (oracle/joint_oracle.py).
+
+Tolerances, fp32: hidden <= 1e-6 absolute (|tanh| <= 1; the GPU uses the device libm tanhf, the CPU
+torch's), logits <= 2e-5 absolute at |logit| ~ 10, gradients <= 1e-5 relative to the largest
+reference entry of the same tensor (sums of up to T*(U+1)*B fp32 terms in a different order).
+bf16/fp16: the result must equal the float64 answer rounded to the dtype within 1 ulp-ish
+(2^-8 / 2^-11 relative).  PARITY UNPINNED (see oracle/joint_oracle.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.joint_oracle import joint_logits
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def rel_to_max(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,T,U1,H", [(2, 5, 4, 512), (1, 33, 3, 320), (3, 16, 1, 7), (2, 17, 5, 1030),
+                                       (1, 1, 1, 4), (2, 40, 6, 2049)])
+def test_joint_hidden_forward_backward_fp32(B, T, U1, H):
+    import rnnt_amd
+
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
+    ep = torch.randn(B, T, H, generator=g) * 1.5
+    dp = torch.randn(B, U1, H, generator=g) * 1.5
+    gh = torch.randn(B, T, U1, H, generator=g)
+    ep64, dp64 = ep.double().requires_grad_(True), dp.double().requires_grad_(True)
+    ref = torch.tanh(ep64[:, :, None, :] + dp64[:, None, :, :])
+    ref.backward(gh.double())
+
+    e, d = ep.to(DEV).requires_grad_(True), dp.to(DEV).requires_grad_(True)
+    h = rnnt_amd.joint_hidden(e, d)
+    assert h.shape == (B, T, U1, H) and h.dtype is torch.float32 and h.is_contiguous()
+    h.backward(gh.to(DEV))
+    assert (h.detach().cpu().double() - ref.detach()).abs().max() <= 1e-6
+    assert rel_to_max(e.grad.cpu().double(), ep64.grad) <= 1e-5
+    assert rel_to_max(d.grad.cpu().double(), dp64.grad) <= 1e-5
+
+
+def test_joint_hidden_backward_is_bitwise_reproducible_and_ordered():
+    import rnnt_amd
+
+    g = torch.Generator().manual_seed(5)
+    e = (torch.randn(2, 70, 512, generator=g)).to(DEV).requires_grad_(True)
+    d = (torch.randn(2, 9, 512, generator=g)).to(DEV).requires_grad_(True)
+    gh = torch.randn(2, 70, 9, 512, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        e.grad = d.grad = None
+        rnnt_amd.joint_hidden(e, d).backward(gh)
+        outs.append((e.grad.clone(), d.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dtype,eps", [(torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)])
+def test_joint_hidden_half_precision(dtype, eps):
+    import rnnt_amd
+
+    g = torch.Generator().manual_seed(11)
+    ep = (torch.randn(2, 19, 512, generator=g)).to(dtype)
+    dp = (torch.randn(2, 4, 512, generator=g)).to(dtype)
+    gh = torch.randn(2, 19, 4, 512, generator=g).to(dtype)
+    ep64, dp64 = ep.double().requires_grad_(True), dp.double().requires_grad_(True)
+    ref = torch.tanh(ep64[:, :, None, :] + dp64[:, None, :, :])
+    e, d = ep.to(DEV).requires_grad_(True), dp.to(DEV).requires_grad_(True)
+    h = rnnt_amd.joint_hidden(e, d)
+    assert h.dtype is dtype
+    h.backward(gh.to(DEV))
+    assert (h.detach().cpu().double() - ref.detach()).abs().max() <= eps
+    # the kernel multiplies by 1 - h^2 with h as STORED (rounded to the dtype), as autograd through a
+    # half-precision Tanh does; the stored value may sit one rounding step from torch's in near-ties
+    hq = h.detach().cpu().double()
+    gpre = gh.double() * (1 - hq * hq)
+    ge, gd = gpre.sum(2), gpre.sum(1)
+    assert ((e.grad.cpu().double() - ge).abs() <= 2 * eps * ge.abs() + 1e-6).all()
+    assert ((d.grad.cpu().double() - gd).abs() <= 2 * eps * gd.abs() + 1e-6).all()
+
+
+@pytest.mark.parametrize("joint", ["concat", "sum"])
+def test_jointnet_module_against_reference_restatement(joint):
+    """rnnt_amd.JointNet == the reference's JointNet on the same weights: logits and every gradient."""
+    import rnnt_amd
+
+    torch.manual_seed(21)
+    B, T, U1, He, Hd, H, V = 2, 11, 5, 40, (40 if joint == "sum" else 24), 64, 37
+    nin = He if joint == "sum" else He + Hd
+    net = rnnt_amd.JointNet(nin, H, V, joint=joint)
+    enc, dec = torch.randn(B, T, He), torch.randn(B, U1, Hd)
+    gl = torch.randn(B, T, U1, V)
+
+    p64 = [p.detach().double().requires_grad_(True) for p in net.parameters()]
+    e64, d64 = enc.double().requires_grad_(True), dec.double().requires_grad_(True)
+    ref = joint_logits(e64, d64, *p64, joint=joint)
+    ref.backward(gl.double())
+
+    net = net.to(DEV)
+    e, d = enc.to(DEV).requires_grad_(True), dec.to(DEV).requires_grad_(True)
+    out = net(e, d)
+    out.backward(gl.to(DEV))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() <= 2e-5
+    assert rel_to_max(e.grad.cpu().double(), e64.grad) <= 1e-5
+    assert rel_to_max(d.grad.cpu().double(), d64.grad) <= 1e-5
+    for p, q in zip(net.parameters(), p64):
+        assert rel_to_max(p.grad.cpu().double(), q.grad) <= 1e-5
+    # pre-unsqueezed 4-D states (model.py:46-50) take the same path
+    out4 = net(e.detach().unsqueeze(2), d.detach().unsqueeze(1))
+    assert torch.equal(out4, out.detach())
+
+
+def test_joint_then_loss_end_to_end_against_oracles():
+    """The reference's two lines model.py:115-116 — joint, then RNNTLoss — on the MI355X path against
+    the CPU restatements of both, down to the gradient of the encoder and decoder states."""
+    import rnnt_amd
+
+    torch.manual_seed(4)
+    B, T, U, He, Hd, H, V = 3, 12, 4, 16, 8, 32, 29
+    net = rnnt_amd.JointNet(He + Hd, H, V)
+    enc, dec = torch.randn(B, T, He), torch.randn(B, U + 1, Hd)
+    rng = np.random.default_rng(9)
+    labels = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    al = np.array([T, 7, 10], np.int32)
+    ll = np.array([U, 2, 4], np.int32)
+
+    params = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    e32, d32 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    logits = joint_logits(e32, d32, *params)
+    c, g, _ = oracle.rnnt_loss_c(logits.detach().numpy(), labels, al, ll)
+    ref_loss, ref_g = oracle.reduce_like_upstream(c, g, "mean", 1.0)
+    logits.backward(torch.from_numpy(ref_g))
+
+    net = net.to(DEV)
+    e, d = enc.to(DEV).requires_grad_(True), dec.to(DEV).requires_grad_(True)
+    loss = rnnt_amd.RNNTLoss()(net(e, d), torch.from_numpy(labels).to(DEV), torch.from_numpy(al).to(DEV),
+                               torch.from_numpy(ll).to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss[0]) <= 1e-5 * abs(ref_loss[0])
+    assert rel_to_max(e.grad.cpu(), e32.grad) <= 1e-4
+    assert rel_to_max(d.grad.cpu(), d32.grad) <= 1e-4
+    for p, q in zip(net.parameters(), params):
+        assert rel_to_max(p.grad.cpu(), q.grad) <= 1e-4
+
+
+def test_joint_hidden_config2_size():
+    """B32 T400 U40 H512 (the reference's joint at BASELINE config 2): 268 M outputs, checked against
+    the same expression evaluated by torch on the device, and the reductions against torch sums."""
+    import rnnt_amd
+
+    g = torch.Generator(device=DEV).manual_seed(2)
+    e = torch.randn(32, 400, 512, device=DEV, generator=g).requires_grad_(True)
+    d = torch.randn(32, 41, 512, device=DEV, generator=g).requires_grad_(True)
+    h = rnnt_amd.joint_hidden(e, d)
+    ref = torch.tanh(e.detach()[:, :, None, :] + d.detach()[:, None, :, :])
+    assert (h.detach() - ref).abs().max().item() <= 1e-6
+    gh = torch.randn(h.shape, device=DEV, generator=g)
+    h.backward(gh)
+    gpre = gh * (1 - ref * ref)
+    assert rel_to_max(e.grad, gpre.sum(2)) <= 1e-5
+    assert rel_to_max(d.grad.double(), gpre.double().sum(1)) <= 1e-5
+
+
+def test_joint_hidden_argument_checks():
+    import rnnt_amd
+
+    e = torch.zeros(2, 3, 8, device=DEV)
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_hidden(e, torch.zeros(3, 4, 8, device=DEV))
+    with pytest.raises(TypeError):
+        rnnt_amd.joint_hidden(e, torch.zeros(2, 4, 8, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        rnnt_amd.joint_hidden(e.cpu(), torch.zeros(2, 4, 8))

@@ -1,0 +1,58 @@
+"""CPU tests (no GPU) for the joint-network widening: the identity the HIP path relies on, and the
+C ABI's host-side argument checks."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle.joint_oracle import joint_logits
+
+
+@pytest.mark.parametrize("joint", ["concat", "sum"])
+def test_split_linear_identity_float64(joint):
+    """Linear(cat(e, d)) == W_e e + W_d d + b: the decomposition rnnt_amd.JointNet uses."""
+    g = torch.Generator().manual_seed(3)
+    B, T, U1, He, Hd, H, V = 2, 5, 4, 6, (6 if joint == "sum" else 3), 8, 7
+    enc = torch.randn(B, T, He, generator=g, dtype=torch.float64)
+    dec = torch.randn(B, U1, Hd, generator=g, dtype=torch.float64)
+    nin = He if joint == "sum" else He + Hd
+    w1 = torch.randn(H, nin, generator=g, dtype=torch.float64)
+    b1 = torch.randn(H, generator=g, dtype=torch.float64)
+    w2 = torch.randn(V, H, generator=g, dtype=torch.float64)
+    b2 = torch.randn(V, generator=g, dtype=torch.float64)
+    ref, hid = joint_logits(enc, dec, w1, b1, w2, b2, joint, return_hidden=True)
+    we, wd = (w1, w1) if joint == "sum" else (w1[:, :He], w1[:, He:])
+    ep = torch.nn.functional.linear(enc, we, b1)
+    dp = torch.nn.functional.linear(dec, wd)
+    mine = torch.tanh(ep[:, :, None, :] + dp[:, None, :, :])
+    assert (mine - hid).abs().max() < 1e-13
+    assert ref.shape == (B, T, U1, V)
+
+
+def test_module_mirrors_reference_parameter_names():
+    import rnnt_amd
+
+    m = rnnt_amd.JointNet(640, 512, 4232)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {
+        "mlp.0.weight": (512, 640), "mlp.0.bias": (512,), "mlp.2.weight": (4232, 512), "mlp.2.bias": (4232,)}
+    with pytest.raises(ValueError, match="must be have same size"):
+        m(torch.zeros(1, 2, 320), torch.zeros(320))
+    with pytest.raises(RuntimeError, match="no CPU"):   # the training path has no CPU implementation
+        m(torch.zeros(1, 2, 320), torch.zeros(1, 3, 320))
+    # the evaluation path (model.py:51-54, 1-D / 2-D states) is plain torch and runs anywhere
+    out = m(torch.zeros(320), torch.zeros(320))
+    assert out.shape == (4232,)
+    with pytest.raises(AttributeError):                 # model.py:60-61: self.softmax does not exist upstream either
+        m(torch.zeros(320), torch.zeros(320), softmax=True)
+
+
+def test_joint_abi_rejects_bad_arguments_without_a_gpu():
+    from rnnt_amd import _lib
+
+    lib = _lib.load()
+    n = ctypes.c_size_t(0)
+    assert lib.rnnt_joint_hidden_workspace_size(32, 400, 41, 512, ctypes.byref(n)) == 0
+    assert n.value == 32 * 25 * 41 * 512 * 4            # one fp32 row per (b, 16-frame chunk, u)
+    assert lib.rnnt_joint_hidden_workspace_size(0, 400, 41, 512, ctypes.byref(n)) != 0
+    assert lib.rnnt_joint_hidden_forward(None, None, None, 1, 1, 1, 1, 0, None) != 0
+    assert lib.rnnt_joint_hidden_backward(None, None, None, None, 1, 1, 1, 1, 0, None, None) != 0
