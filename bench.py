@@ -107,7 +107,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["custom"])
+    ap.add_argument("--shape", default=None,
+                    help="with --workload custom: B,T,U,V,dtype[,ragged]  e.g. 64,400,40,128,f32 (tuning sweeps; "
+                         "not a BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-b", type=int, default=16)
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -147,7 +150,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
 
-    w = dict(WORKLOADS[args.workload])
+    if args.workload == "custom":
+        f = (args.shape or "").split(",")
+        if len(f) < 5:
+            raise SystemExit("--workload custom needs --shape B,T,U,V,dtype[,ragged]")
+        w = dict(B=int(f[0]), T=int(f[1]), U=int(f[2]), V=int(f[3]), dtype=f[4], ragged=len(f) > 5 and f[5] == "ragged")
+    else:
+        w = dict(WORKLOADS[args.workload])
     B = w["B"]
     acts, labels, al_d, ll_d, al, ll = make_device_batch(w, dev, first_utt=rank * B)
     acts.requires_grad_(True)
@@ -272,7 +281,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # free the device tensors' host shadows first; the CPU sample needs a few GB of RAM
-        out["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], args.cpu_sample_b, args.cpu_reps)
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample_b, args.cpu_reps)
     elif rank == 0:
         out["cpu_baseline"] = None
     sys.stdout.flush()

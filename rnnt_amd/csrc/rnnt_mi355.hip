@@ -193,6 +193,89 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     }
 }
 
+// Rows too long for four waves' registers (more than 4*17*64 chunks = 69 632 bytes, e.g. V = 32 768
+// fp32): one workgroup per node streams the row ONCE, 8 chunks per thread at a time, with a running
+// {max, sum}: the sum is rescaled when a batch raises the max (one extra exp2 per 32..64 logits).
+template <typename DT>
+__global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
+    const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
+    const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
+    int V, int blank, long long total_rows) {
+    constexpr int EPC = DT::EPC;
+    constexpr int UNR = 8;
+    __shared__ float red_m[4], red_s[4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and 16-byte aligned rows
+    auto safe = [](float m) { return (m == -INFINITY || m == INFINITY) ? 0.0f : m; };  // as rnnt_k1_lse
+
+    for (long long r = blockIdx.x; r < total_rows; r += gridDim.x) {  // host launches one workgroup per node
+        const RowCoord c = decode_row(r, maxT, U1);
+        const int Tb = act_lens[c.b];
+        const int Ub = label_lens[c.b];
+        if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) continue;  // workgroup-uniform
+        const typename DT::elem *row = acts + (size_t)r * (size_t)V;
+        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
+
+        float m = -INFINITY, s = 0.0f;
+        for (int base = threadIdx.x; base < nchunks; base += 256 * UNR) {
+            u32x4 raw[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {  // unconditional loads: a surplus slot re-reads the last chunk
+                const int idx = base + k * 256;
+                raw[k] = __builtin_nontemporal_load(row4 + (idx < nchunks ? idx : nchunks - 1));
+            }
+            float bm = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                float x[EPC];
+                DT::unpack(raw[k], x);
+                const bool in = base + k * 256 < nchunks;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) bm = fmaxf(bm, in ? x[j] : -INFINITY);
+            }
+            const float m_new = fmaxf(m, bm);
+            const float mm = safe(m_new);
+            s = (s == 0.0f) ? 0.0f : s * __builtin_amdgcn_exp2f((safe(m) - mm) * kLog2e);
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                float x[EPC];
+                DT::unpack(raw[k], x);
+                const bool in = base + k * 256 < nchunks;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) s += in ? __builtin_amdgcn_exp2f((x[j] - mm) * kLog2e) : 0.0f;
+            }
+            m = m_new;
+        }
+        // combine the 256 running pairs: lanes, then waves (fixed order: reproducible)
+        float M = wave_max(m);
+        s = (s == 0.0f) ? 0.0f : s * __builtin_amdgcn_exp2f((safe(m) - safe(M)) * kLog2e);
+        s = wave_sum(s);
+        if (lane == 0) {
+            red_m[wave] = M;
+            red_s[wave] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float MM = red_m[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) MM = fmaxf(MM, red_m[i]);
+            const float mm = safe(MM);
+            float S = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                S += (red_s[i] == 0.0f) ? 0.0f : red_s[i] * __builtin_amdgcn_exp2f((safe(red_m[i]) - mm) * kLog2e);
+            const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
+            const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
+            const float logs = __logf(S);
+            const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+            L.ml[o] = make_float2(mm, logs);
+            L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (c.u < Ub) ? (xy - mm) - logs : -INFINITY);
+        }
+        __syncthreads();  // red_* are reused by the next node of a grid-stride launch
+    }
+}
+
 // Fallback for any V / alignment (element-granular loads, two passes over an L2-resident row).
 template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
@@ -691,10 +774,16 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
         else                                                                                           \
             hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 4>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
         break;
+    const bool vectorisable = V % DT::EPC == 0 && reinterpret_cast<uintptr_t>(acts) % 16 == 0;
     switch (t.nch) {
         FOR_EACH_NCH(CASE)
         default:
-            hipLaunchKernelGGL((rnnt_k1_lse_generic<DT>), dim3(grid), dim3(block), 0, st, K1_ARGS);
+            if (vectorisable) {  // row longer than 4 waves hold: one workgroup per node, single streaming pass
+                const int wgrid = g > 0 ? g : (int)(rows > 0x7fffffffLL ? 0x7fffffffLL : rows);
+                hipLaunchKernelGGL((rnnt_k1_lse_wide<DT>), dim3(wgrid), dim3(block), 0, st, K1_ARGS);
+            } else {
+                hipLaunchKernelGGL((rnnt_k1_lse_generic<DT>), dim3(grid), dim3(block), 0, st, K1_ARGS);
+            }
     }
 #undef CASE
 #undef K1_ARGS

@@ -88,10 +88,12 @@ def test_small_ragged_vs_oracle(B, T, U, V, seed, reduction):
     check_against_oracle(acts, labels, al, ll, reduction, go)
 
 
-@pytest.mark.parametrize("V", [5, 6, 7, 4234, 4232, 4100, 4352, 8200, 8196, 16384, 17408, 20000])
+@pytest.mark.parametrize("V", [5, 6, 7, 4234, 4232, 4100, 4352, 8200, 8196, 16384, 17408, 17412, 20000, 32768,
+                               65536, 70001])
 def test_vocab_sizes_and_alignment(V):
     # V % 4 != 0 -> element-granular fallback; 4352 = exactly 17 chunks/lane; 8200 -> two waves per
-    # node in K1 and two segments in K3; 16384/17408 -> four; 20000 -> K1 fallback, five K3 segments
+    # node in K1 and two segments in K3; 16384 -> four; from 17408 on K1 streams the row with one
+    # workgroup per node (running max/sum); 20000 -> five K3 segments
     acts, labels, al, ll = make_case(2, 9, 4, V, seed=V, ragged=True)
     check_against_oracle(acts, labels, al, ll, "mean", 0.5)
 
@@ -146,6 +148,20 @@ def test_masked_vocabulary_entries_minus_inf():
     labels = np.minimum(labels, 16).astype(np.int32)
     loss, grads = check_against_oracle(acts, labels, al, ll, "mean", 1.0)
     assert np.isfinite(loss).all() and np.all(grads[..., 17:] == 0)
+
+
+def test_wide_row_running_max_edge_cases():
+    """V = 32768 takes K1's single-pass kernel: the running {max, sum} must survive a max that rises by
+    hundreds late in the row, -inf stretches, a large common offset, and a NaN."""
+    acts, labels, al, ll = make_case(2, 3, 2, 32768, seed=46, ragged=False)
+    acts[0, :, :, :30000] -= 400.0        # first batches far below the final max
+    acts[0, 1, 1, :32000] = -np.inf       # whole batches of -inf before finite values
+    acts[1] += 1e4
+    labels[0, :] = [32001, 32002]
+    check_against_oracle(acts, labels, al, ll, "none", np.ones(2, np.float32))
+    acts[1, 2, 0, 31999] = np.nan
+    loss, _ = run_gpu(acts, labels, al, ll, "none", np.ones(2, np.float32))
+    assert np.isfinite(loss[0]) and np.isnan(loss[1])
 
 
 def test_extreme_logit_scale():
