@@ -61,6 +61,31 @@ __device__ __forceinline__ int row_misalign(const void *p) {
     return (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);
 }
 
+// Rows that are not 16-byte aligned (V*elem % 16 != 0, e.g. the reference's V = 4234 and 5455):
+// the wave still moves whole aligned 16-byte chunks; `s` elements of the previous row share the
+// first chunk and some of the next row share the last one.  Only those two chunks need care.
+template <typename DT>
+__device__ __forceinline__ u32x4 mask_outside_row(const u32x4 &raw, int first, int V) {
+    // elements whose row index first+j is outside [0,V) become -inf (max and sum-exp ignore them)
+    float x[DT::EPC];
+    DT::unpack(raw, x);
+#pragma unroll
+    for (int j = 0; j < DT::EPC; ++j)
+        if ((unsigned)(first + j) >= (unsigned)V) x[j] = -INFINITY;
+    return DT::pack(x);
+}
+template <typename DT>
+__device__ __forceinline__ void store_inside_row(const u32x4 &v, u32x4 *p, int first, int V) {
+    // element-wise stores of the part of a boundary chunk that belongs to this row
+    typedef typename DT::elem E;
+    E tmp[DT::EPC];
+    __builtin_memcpy(tmp, &v, 16);
+    E *o = reinterpret_cast<E *>(p);
+#pragma unroll
+    for (int j = 0; j < DT::EPC; ++j)
+        if ((unsigned)(first + j) < (unsigned)V) o[j] = tmp[j];
+}
+
 struct Lattice {      // device pointers into the workspace
     float2 *ml;       // {max_v x_v, log sum_v exp(x_v - max)} per node, kept apart: lse = m + l would
                       // round to ulp(|m|) and cost K3 that much relative accuracy on offset logits
@@ -93,7 +118,7 @@ struct Lattice {      // device pointers into the workspace
     return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 6 : 8;
 }
 
-template <typename DT, int NCH, int WPR>
+template <typename DT, int NCH, int WPR, bool MIS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC), k1_waves(NCH, DT::EPC))))
 void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ labels,
@@ -109,7 +134,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     const int wave = threadIdx.x / kWave;
     const int rib = wave / WPR;
     const int seg = wave - rib * WPR;
-    const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and nchunks <= WPR*NCH*64
+    // !MIS: host guarantees V % EPC == 0, 16-byte aligned rows and V/EPC <= WPR*NCH*64 - 7
     const long long ngroups = (total_rows + RPB - 1) / RPB;
 
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {  // host launches ngroups blocks
@@ -122,7 +147,10 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         if (WPR == 1 && !valid) continue;
 
         const typename DT::elem *row = acts + (size_t)(valid ? r : 0) * (size_t)V;
-        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
+        const int shift = MIS ? (int)((addr & 15) / sizeof(typename DT::elem)) : 0;  // previous row's elements in chunk 0
+        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (addr & ~(uintptr_t)15) : addr);
+        const int nchunks = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
         // Chunk index of lane 0 is shifted back so that every wave-instruction covers one
         // 128-byte-aligned KiB of memory whatever the row's own alignment (rows are only 16-byte
         // aligned: V*elem need not be a multiple of 128).
@@ -132,6 +160,14 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
             if (valid && idx >= 0 && idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
+        }
+        if (MIS) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int idx = c0 + k * kWave;
+                if (valid && (idx == 0 || idx == nchunks - 1))  // at most two lanes of the wave
+                    raw[k] = mask_outside_row<DT>(raw[k], idx * EPC - shift, V);
+            }
         }
         // blank / label logits: tiny extra loads that hit the lines fetched above
         const int y = (valid && c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
@@ -525,7 +561,7 @@ __device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &
 // turned out to be sensitive to VALU work (+2 ops per logit cost 7 %).
 template <typename DT>
 __device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, const NodeCoef &n, float nl2, bool hit_b,
-                                            int lane_b, bool hit_y, int lane_y, int lane, int blank) {
+                                            int lane_b, bool hit_y, int lane_y, int lane, int jb, int jy) {
     constexpr int EPC = DT::EPC;
     float x[EPC];
     DT::unpack(raw, x);
@@ -546,13 +582,13 @@ __device__ __forceinline__ u32x4 grad_chunk(const u32x4 &raw, const NodeCoef &n,
         // compiler otherwise if-converts it into 2 VALU ops per logit on every chunk
         const float sub = (lane == lane_b) ? n.sbk : 0.0f;
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) x[j] -= (j == (blank & (EPC - 1))) ? sub : 0.0f;
+        for (int j = 0; j < EPC; ++j) x[j] -= (j == jb) ? sub : 0.0f;
     }
     if (hit_y) {
         asm volatile("; label-logit correction" ::: "memory");
         const float sub = (lane == lane_y) ? n.syk : 0.0f;
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) x[j] -= (j == (n.y & (EPC - 1))) ? sub : 0.0f;
+        for (int j = 0; j < EPC; ++j) x[j] -= (j == jy) ? sub : 0.0f;
     }
     return DT::pack(x);
 }
@@ -571,7 +607,7 @@ __device__ __forceinline__ void st16(const u32x4 &v, u32x4 *p) {
         *p = v;
 }
 
-template <typename DT, int NCH, bool NTL = true, bool NTS = true>
+template <typename DT, int NCH, bool MIS = false, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH, DT::EPC), k3_waves(NCH, DT::EPC))))
 void rnnt_k3_grad(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
@@ -583,7 +619,6 @@ void rnnt_k3_grad(
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    const int nchunks = V / EPC;
     const long long nitems = total_rows * nseg;  // a work item = NCH*64 consecutive chunks of one node
 
     for (long long wi = wave0; wi < nitems; wi += nwaves) {  // host launches one wave per item
@@ -591,7 +626,12 @@ void rnnt_k3_grad(
         const RowCoord c = decode_row(r, maxT, U1);
         const int Tb = act_lens[c.b];
         const int Ub = label_lens[c.b];
-        u32x4 *out4 = reinterpret_cast<u32x4 *>(grads + (size_t)r * (size_t)V);
+        // MIS: rows are not 16-byte aligned (host guarantees acts and grads share the misalignment);
+        // `shift` elements of the previous row sit in chunk 0, see mask_outside_row
+        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(grads + (size_t)r * (size_t)V);
+        const int shift = MIS ? (int)((oaddr & 15) / sizeof(typename DT::elem)) : 0;
+        u32x4 *out4 = reinterpret_cast<u32x4 *>(MIS ? (oaddr & ~(uintptr_t)15) : oaddr);
+        const int nchunks = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
         // lane 0 shifted back so each wave-instruction covers a 128-byte-aligned KiB (see K1)
         const int c0 = (int)(wi - r * nseg) * NCH * kWave + lane - row_misalign(out4);
         if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) {
@@ -599,11 +639,17 @@ void rnnt_k3_grad(
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const int idx = c0 + k * kWave;
-                if (idx >= 0 && idx < nchunks) st16<NTS>(z, out4 + idx);
+                if (idx >= 0 && idx < nchunks) {
+                    if (MIS && (idx == 0 || idx == nchunks - 1))
+                        store_inside_row<DT>(z, out4 + idx, idx * EPC - shift, V);
+                    else
+                        st16<NTS>(z, out4 + idx);
+                }
             }
             continue;
         }
-        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(acts + (size_t)r * (size_t)V);
+        const uintptr_t iaddr = reinterpret_cast<uintptr_t>(acts + (size_t)r * (size_t)V);
+        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (iaddr & ~(uintptr_t)15) : iaddr);
         u32x4 raw[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -612,19 +658,26 @@ void rnnt_k3_grad(
         }
         const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
         const float nl2 = -n.l * kLog2e;  // softmax_v = 2^((x_v - m)*log2e - l*log2e)
-        // which wave-instruction k / lane holds the blank and the label logit (wave-uniform)
+        // which wave-instruction k / lane / element holds the blank and the label logit (wave-uniform)
         const int base = __builtin_amdgcn_readfirstlane(c0 - lane);
-        const int rel_b = blank / EPC - base;
-        const int rel_y = (n.y >= 0 ? n.y / EPC : -(1 << 20)) - base;
+        const int pos_b = blank + shift;
+        const int pos_y = n.y >= 0 ? n.y + shift : -(1 << 24);
+        const int rel_b = pos_b / EPC - base;
+        const int rel_y = (pos_y >= 0 ? pos_y / EPC : -(1 << 20)) - base;
         const int kb = __builtin_amdgcn_readfirstlane(rel_b >= 0 ? rel_b >> 6 : -1);
         const int ky = __builtin_amdgcn_readfirstlane(rel_y >= 0 ? rel_y >> 6 : -1);
         const int lane_b = rel_b & (kWave - 1), lane_y = rel_y & (kWave - 1);
+        const int jb = pos_b & (EPC - 1), jy = pos_y & (EPC - 1);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int idx = c0 + k * kWave;
-            if (idx >= 0 && idx < nchunks)
-                st16<NTS>(grad_chunk<DT>(raw[k], n, nl2, k == kb, lane_b, k == ky, lane_y, lane, blank),
-                          out4 + idx);
+            if (idx >= 0 && idx < nchunks) {
+                const u32x4 g = grad_chunk<DT>(raw[k], n, nl2, k == kb, lane_b, k == ky, lane_y, lane, jb, jy);
+                if (MIS && (idx == 0 || idx == nchunks - 1))
+                    store_inside_row<DT>(g, out4 + idx, idx * EPC - shift, V);
+                else
+                    st16<NTS>(g, out4 + idx);
+            }
         }
     }
 }
@@ -705,19 +758,24 @@ bool check_common(const void *acts, const int *labels, const int *act_lens, cons
 struct Tile {
     int nch;   // chunks per lane, one of kNchSizes; 0 = use the element-granular fallback
     int nseg;  // segments (waves) per node
+    bool mis;  // rows are not 16-byte aligned: the MIS kernels (boundary chunks masked / stored by element)
 };
 constexpr int kNchSizes[] = {1, 2, 4, 6, 8, 12, 16, 17};
 inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_seg) {
-    Tile t = {0, 0};
+    Tile t = {0, 0, false};
     const int epc = 16 / elem_size(dtype);
-    if (V % epc != 0) return t;
-    if (reinterpret_cast<uintptr_t>(p0) % 16 != 0) return t;
-    if (p1 && reinterpret_cast<uintptr_t>(p1) % 16 != 0) return t;
-    const int need = (V / epc + 7 + kWave - 1) / kWave;  // chunks per lane if one wave took the whole row
-                                                         // (+7: the 128-byte alignment shift)
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(p0) % 16, a1 = p1 ? reinterpret_cast<uintptr_t>(p1) % 16 : a0;
+    if (a0 != a1) return t;  // logits and gradient rows must share their misalignment
+    t.mis = V % epc != 0 || a0 != 0;
+    // chunks per lane if one wave took the whole row (+7: the 128-byte alignment shift; MIS: a row
+    // can straddle one more chunk)
+    const int need = ((V + epc - 1) / epc + (t.mis ? 1 : 0) + 7 + kWave - 1) / kWave;
     int nseg = (need + 16) / 17;
     if (max_seg == 4 && nseg == 3) nseg = 4;  // K1 splits a workgroup of 4 waves evenly
-    if (nseg > max_seg) return t;
+    if (nseg > max_seg) {
+        t.mis = false;
+        return t;
+    }
     const int per = (need + nseg - 1) / nseg;
     for (int sz : kNchSizes)
         if (per <= sz) {
@@ -765,14 +823,16 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     const int g = tuning_knob("RNNT_K1_GRID", 0);
     if (g > 0) grid = g;
 #define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
+#define K1_LAUNCH(N, W, M) hipLaunchKernelGGL((rnnt_k1_lse<DT, N, W, M>), dim3(grid), dim3(block), 0, st, K1_ARGS)
 #define CASE(N)                                                                                        \
     case N:                                                                                            \
-        if (t.nseg == 1)                                                                               \
-            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 1>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
-        else if (t.nseg == 2)                                                                          \
-            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 2>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
-        else                                                                                           \
-            hipLaunchKernelGGL((rnnt_k1_lse<DT, N, 4>), dim3(grid), dim3(block), 0, st, K1_ARGS);      \
+        if (t.nseg == 1) {                                                                             \
+            if (t.mis) K1_LAUNCH(N, 1, true); else K1_LAUNCH(N, 1, false);                             \
+        } else if (t.nseg == 2) {                                                                      \
+            if (t.mis) K1_LAUNCH(N, 2, true); else K1_LAUNCH(N, 2, false);                             \
+        } else {                                                                                       \
+            if (t.mis) K1_LAUNCH(N, 4, true); else K1_LAUNCH(N, 4, false);                             \
+        }                                                                                              \
         break;
     const bool vectorisable = V % DT::EPC == 0 && reinterpret_cast<uintptr_t>(acts) % 16 == 0;
     switch (t.nch) {
@@ -786,6 +846,7 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
             }
     }
 #undef CASE
+#undef K1_LAUNCH
 #undef K1_ARGS
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
@@ -810,7 +871,10 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
     switch (t.nch) {
 #define CASE(N)                                                                                       \
     case N:                                                                                           \
-        hipLaunchKernelGGL((rnnt_k3_grad<DT, N>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg); \
+        if (t.mis)                                                                                    \
+            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, true>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, false>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg); \
         break;
         FOR_EACH_NCH(CASE)
 #undef CASE

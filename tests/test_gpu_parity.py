@@ -150,6 +150,51 @@ def test_masked_vocabulary_entries_minus_inf():
     assert np.isfinite(loss).all() and np.all(grads[..., 17:] == 0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V", [1, 2, 3, 9, 4233, 4234, 5455, 8201])
+def test_rows_not_16_byte_aligned(dtype, V):
+    """The reference's own vocabularies include 4234 and 5455 (egs/aishell/exp train.log, config/magic_*):
+    V*elem is then no multiple of 16 and rows start at every element offset of a 16-byte chunk.  The
+    kernels move whole aligned chunks and treat the two boundary chunks by element; neighbouring rows
+    (written by other waves) must come out intact, padding rows exactly zero."""
+    B, T, U = 3, 5, 3
+    acts, labels, al, ll = make_case(B, T, U, max(V, 2), seed=900 + V, ragged=True)
+    if V == 1:
+        acts, labels = acts[..., :1].copy(), np.zeros_like(labels)     # only blank exists: labels unused below
+        ll[:] = 0
+    q = torch.from_numpy(acts).to(dtype).float().numpy()
+    c, g, _ = oracle.rnnt_loss_c(q, labels, al, ll)
+    ref_loss, ref_g = oracle.reduce_like_upstream(c, g, "sum", 1.0)
+    loss, grads = run_gpu(q, labels, al, ll, "sum", 1.0, dtype=dtype)
+    np.testing.assert_allclose(loss, ref_loss, rtol=LOSS_RTOL)
+    eps = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    assert np.all(np.abs(grads - ref_g) <= GRAD_ATOL + eps * np.abs(ref_g))
+    assert np.all((grads == 0) | (ref_g != 0) | (np.abs(grads) <= GRAD_ATOL))
+    for b in range(B):                                                 # padding stays exactly zero
+        assert np.all(grads[b, al[b]:] == 0) and np.all(grads[b, :, ll[b] + 1:] == 0)
+
+
+def test_sliced_batch_with_misaligned_base_pointer():
+    """acts[1:] of a V=4233 tensor starts 12 bytes off a 16-byte boundary while autograd's fresh gradient
+    buffer is aligned: logits and gradient rows then differ in misalignment, which the chunked kernels do
+    not take (K1 does, K3 falls back to the element-granular kernel)."""
+    import rnnt_amd
+
+    acts, labels, al, ll = make_case(3, 5, 2, 4234 + 1, seed=77, ragged=True)
+    acts = acts[..., :4233].copy()                                     # 4233*4 bytes per row: odd dword count
+    labels = np.minimum(labels, 4232).astype(np.int32)
+    dev = torch.device("cuda:0")
+    full = torch.from_numpy(acts).to(dev)
+    a = full[1:].detach().requires_grad_(True)                          # contiguous view, base % 16 != 0
+    assert a.data_ptr() % 16 != 0 and a.is_contiguous()
+    loss = rnnt_amd.RNNTLoss(reduction="sum")(a, torch.from_numpy(labels[1:]).to(dev),
+                                              torch.from_numpy(al[1:]).to(dev), torch.from_numpy(ll[1:]).to(dev))
+    loss.backward()
+    c, g, _ = oracle.rnnt_loss_c(acts[1:], labels[1:], al[1:], ll[1:])
+    np.testing.assert_allclose(loss.item(), c.sum(), rtol=LOSS_RTOL)
+    assert np.abs(a.grad.cpu().numpy() - g).max() <= GRAD_ATOL
+
+
 def test_wide_row_running_max_edge_cases():
     """V = 32768 takes K1's single-pass kernel: the running {max, sum} must survive a max that rises by
     hundreds late in the row, -inf stretches, a large common offset, and a NaN."""
