@@ -131,7 +131,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     constexpr int RPB = WPB / WPR;  // nodes per workgroup
     __shared__ float red[2][WPB];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    const int wave = threadIdx.x / kWave;  // (left in a VGPR: forcing it scalar measured 1.6 % slower here)
     const int rib = wave / WPR;
     const int seg = wave - rib * WPR;
     // !MIS: host guarantees V % EPC == 0, 16-byte aligned rows and V/EPC <= WPR*NCH*64 - 7
@@ -229,6 +229,151 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small rows (up to 256 chunks, i.e. V <= ~1000 fp32 / ~2000 16-bit; char and small word-piece
+// vocabularies).  One wave per node is latency-bound there: a wave has one short row in flight and
+// spends ~7k cycles on the dependent chain lengths -> row -> reductions -> store.  These variants
+// give a wave G*NR consecutive nodes per iteration: LPR lanes per node (G = 64/LPR nodes side by
+// side, NCH chunks per lane) times NR nodes per lane group, all loads issued before the first reduction.  Rows may
+// start at any element offset of a 16-byte chunk (V = 29: 116-byte rows); boundary chunks are
+// masked on the way in and stored by element on the way out, exactly as in the MIS variants above.
+// ---------------------------------------------------------------------------------------------
+struct SmallRow {
+    int b, t, u;     // node
+    int Tb, Ub;      // lengths of its utterance
+    bool valid;      // inside the tensor AND inside the utterance's lattice
+    bool exists;     // inside the tensor (padding nodes exist and get zero gradients)
+};
+// node of row (r0 + o) given the decoded node of r0 (wave-uniform) and a per-lane offset o < 2^16
+// (x + 0.5) * (1/d) truncated is x / d exactly while x < 2^22 (the half keeps the product away from
+// every integer by 0.5/d, far more than the fp32 rounding of it): maxT and maxU are far below that
+__device__ __forceinline__ int small_div(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
+__device__ __forceinline__ SmallRow small_row(const RowCoord &c0, int o, long long r0, long long total_rows,
+                                              const int *__restrict__ act_lens,
+                                              const int *__restrict__ label_lens, int maxT, int U1, int B,
+                                              float inv_T, float inv_U1) {
+    SmallRow s;
+    const int uu = c0.u + o;
+    const int dt = small_div(uu, inv_U1);
+    s.u = uu - dt * U1;
+    const int tt = c0.t + dt;
+    const int db = small_div(tt, inv_T);
+    s.t = tt - db * maxT;
+    s.b = c0.b + db;
+    s.exists = r0 + o < total_rows;
+    const int bb = s.b < B ? s.b : B - 1;
+    s.Tb = act_lens[bb];
+    s.Ub = label_lens[bb];
+    s.valid = s.exists && lens_ok(s.Tb, s.Ub, maxT, U1) && s.t < s.Tb && s.u <= s.Ub;
+    return s;
+}
+
+template <typename DT, int LPR, int NCH, int NR, bool MIS>
+__global__ __launch_bounds__(256) void rnnt_k1_lse_small(
+    const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
+    const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
+    int V, int blank, long long total_rows, int B) {
+    constexpr int EPC = DT::EPC;
+    constexpr int G = kWave / LPR;
+    constexpr int RPW = G * NR;  // nodes per wave iteration
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / LPR, sub = lane % LPR;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
+    const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
+    const long long niter = (total_rows + RPW - 1) / RPW;
+    const float inv_T = 1.0f / (float)maxT, inv_U1 = 1.0f / (float)U1;
+
+    for (long long it = wave0; it < niter; it += nwaves) {  // host launches one wave per iteration
+        const long long r0 = it * RPW;
+        const RowCoord c0 = decode_row(r0, maxT, U1);
+        SmallRow row[NR];
+        u32x4 raw[NR][NCH];
+        int first[NR];   // row index of element 0 of this lane's chunk 0 (negative in the boundary chunk)
+        int nchunks[NR];
+        const typename DT::elem *rowp[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int o = n * G + grp;
+            row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
+            const long long r = row[n].valid ? r0 + o : 0;  // skipped nodes read (and ignore) row 0
+            rowp[n] = acts + (size_t)r * (size_t)V;
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(rowp[n]);
+            const int shift = MIS ? (int)((addr & 15) / sizeof(typename DT::elem)) : 0;
+            const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (addr & ~(uintptr_t)15) : addr);
+            nchunks[n] = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
+            first[n] = sub * EPC - shift;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {  // unconditional loads: surplus lanes re-read the last chunk
+                const int idx = sub + k * LPR;
+                raw[n][k] = __builtin_nontemporal_load(row4 + (idx < nchunks[n] ? idx : nchunks[n] - 1));
+            }
+        }
+        // the two gathered logits and the label, by the leading lane of each group
+        float xb[NR], xy[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            xb[n] = 0.0f;
+            xy[n] = 0.0f;
+            if (sub == 0 && row[n].valid) {
+                const int y = row[n].u < row[n].Ub ? labels[(size_t)row[n].b * (U1 - 1) + row[n].u] : blank;
+                xb[n] = DT::to_float(rowp[n][blank]);
+                xy[n] = (y >= 0 && y < V) ? DT::to_float(rowp[n][y]) : __builtin_nanf("");
+            }
+        }
+        float m[NR], s[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            m[n] = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                float x[EPC];
+                DT::unpack(raw[n][k], x);
+                const int e0 = first[n] + k * LPR * EPC;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    // aligned rows: a chunk is inside the row or outside it as a whole
+                    const bool in = MIS ? (unsigned)(e0 + j) < (unsigned)V : e0 < V;
+                    m[n] = fmaxf(m[n], in ? x[j] : -INFINITY);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) m[n] = fmaxf(m[n], __shfl_xor(m[n], off, kWave));
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            m[n] = (m[n] == -INFINITY || m[n] == INFINITY) ? 0.0f : m[n];  // as rnnt_k1_lse
+            s[n] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                float x[EPC];
+                DT::unpack(raw[n][k], x);
+                const int e0 = first[n] + k * LPR * EPC;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    const bool in = MIS ? (unsigned)(e0 + j) < (unsigned)V : e0 < V;
+                    s[n] += in ? __builtin_amdgcn_exp2f((x[j] - m[n]) * kLog2e) : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) s[n] += __shfl_xor(s[n], off, kWave);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            if (sub == 0 && row[n].valid) {
+                const float logs = __logf(s[n]);
+                const size_t o = skew_index(row[n].b, row[n].t, row[n].u, L.ND, L.US);
+                L.ml[o] = make_float2(m[n], logs);
+                L.lp[o] = make_float2((xb[n] - m[n]) - logs,
+                                      row[n].u < row[n].Ub ? (xy[n] - m[n]) - logs : -INFINITY);
+            }
+        }
+    }
+}
+
 // Rows too long for four waves' registers (more than 4*17*64 chunks = 69 632 bytes, e.g. V = 32 768
 // fp32): one workgroup per node streams the row ONCE, 8 chunks per thread at a time, with a running
 // {max, sum}: the sum is rescaled when a batch raises the max (one extra exp2 per 32..64 logits).
@@ -241,7 +386,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
     constexpr int UNR = 8;
     __shared__ float red_m[4], red_s[4];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
     const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and 16-byte aligned rows
     auto safe = [](float m) { return (m == -INFINITY || m == INFINITY) ? 0.0f : m; };  // as rnnt_k1_lse
 
@@ -319,7 +464,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
     const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
     int V, int blank, long long total_rows) {
     const int lane = threadIdx.x & (kWave - 1);
-    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
     for (long long r = wave0; r < total_rows; r += nwaves) {
         const RowCoord c = decode_row(r, maxT, U1);
@@ -397,7 +542,7 @@ __global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(Lattice L, flo
     const int T = act_lens[b];
     const int U = label_lens[b];  // labels; lattice columns 0..U
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
     const int dir = wave / NW;
     const int w = wave - dir * NW;
     const int u = w * kWave + lane;
@@ -617,7 +762,7 @@ void rnnt_k3_grad(
     int nseg) {
     constexpr int EPC = DT::EPC;
     const int lane = threadIdx.x & (kWave - 1);
-    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
     const long long nitems = total_rows * nseg;  // a work item = NCH*64 consecutive chunks of one node
 
@@ -682,6 +827,95 @@ void rnnt_k3_grad(
     }
 }
 
+// K3 for small rows: same node-per-lane-group batching as rnnt_k1_lse_small.
+template <typename DT, int LPR, int NCH, int NR, bool MIS>
+__global__ __launch_bounds__(256) void rnnt_k3_grad_small(
+    const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
+    const int *__restrict__ labels, const int *__restrict__ act_lens,
+    const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
+    int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows, int B) {
+    constexpr int EPC = DT::EPC;
+    constexpr int G = kWave / LPR;
+    constexpr int RPW = G * NR;
+    typedef typename DT::elem E;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int grp = lane / LPR, sub = lane % LPR;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
+    const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
+    const long long niter = (total_rows + RPW - 1) / RPW;
+    const float inv_T = 1.0f / (float)maxT, inv_U1 = 1.0f / (float)U1;
+
+    for (long long it = wave0; it < niter; it += nwaves) {
+        const long long r0 = it * RPW;
+        const RowCoord c0 = decode_row(r0, maxT, U1);
+        SmallRow row[NR];
+        u32x4 raw[NR][NCH];
+        int first[NR], nchunks[NR];
+        u32x4 *out4[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int o = n * G + grp;
+            row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
+            const long long r = row[n].exists ? r0 + o : 0;
+            // host guarantees acts and grads share their misalignment, so one shift serves both
+            const uintptr_t oaddr = reinterpret_cast<uintptr_t>(grads + (size_t)r * (size_t)V);
+            const uintptr_t iaddr = reinterpret_cast<uintptr_t>(acts + (size_t)(row[n].valid ? r : 0) * (size_t)V);
+            const int shift = MIS ? (int)((oaddr & 15) / sizeof(E)) : 0;
+            out4[n] = reinterpret_cast<u32x4 *>(MIS ? (oaddr & ~(uintptr_t)15) : oaddr);
+            const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (iaddr & ~(uintptr_t)15) : iaddr);
+            nchunks[n] = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
+            first[n] = sub * EPC - shift;
+            // = nchunks unless row 0 stands in for a padding node
+            const int in_chunks = MIS ? ((int)((iaddr & 15) / sizeof(E)) + V + EPC - 1) / EPC : V / EPC;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int idx = sub + k * LPR;
+                raw[n][k] = __builtin_nontemporal_load(row4 + (idx < in_chunks ? idx : in_chunks - 1));
+            }
+        }
+        NodeCoef coef[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            if (row[n].valid) {
+                RowCoord c;
+                c.b = row[n].b;
+                c.t = row[n].t;
+                c.u = row[n].u;
+                coef[n] = node_coef(L, c, row[n].Tb, row[n].Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
+            } else {
+                coef[n].sa = coef[n].sbk = coef[n].syk = 0.0f;
+                coef[n].m = coef[n].l = 0.0f;
+                coef[n].y = -1;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            if (!row[n].exists) continue;
+            const float nl2 = -coef[n].l * kLog2e;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int idx = sub + k * LPR;
+                if (idx >= nchunks[n]) continue;
+                const int e0 = first[n] + k * LPR * EPC;
+                float x[EPC];
+                DT::unpack(raw[n][k], x);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    float g = coef[n].sa * __builtin_amdgcn_exp2f(fmaf(x[j] - coef[n].m, kLog2e, nl2));
+                    g -= (e0 + j == blank) ? coef[n].sbk : 0.0f;
+                    g -= (e0 + j == coef[n].y) ? coef[n].syk : 0.0f;
+                    x[j] = row[n].valid ? g : 0.0f;  // padding node: exact zeros (sa = 0 could meet an inf)
+                }
+                const u32x4 g4 = DT::pack(x);
+                if (!MIS || (e0 >= 0 && e0 + EPC <= V))
+                    __builtin_nontemporal_store(g4, out4[n] + idx);
+                else
+                    store_inside_row<DT>(g4, out4[n] + idx, e0, V);
+            }
+        }
+    }
+}
+
 template <typename DT>
 __global__ __launch_bounds__(1024) void rnnt_k3_grad_generic(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
@@ -689,7 +923,7 @@ __global__ __launch_bounds__(1024) void rnnt_k3_grad_generic(
     const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
     int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows) {
     const int lane = threadIdx.x & (kWave - 1);
-    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
     for (long long r = wave0; r < total_rows; r += nwaves) {
         const RowCoord c = decode_row(r, maxT, U1);
@@ -811,6 +1045,24 @@ inline int tuning_knob(const char *name, int dflt) {
 
 #define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)
 
+// Small rows: shape index into {LPR, NCH, NR} = {8,1,8} {8,2,4} {8,4,2} {8,8,1} {8,16,1}, or -1 when a
+// row can span more than 128 chunks (the one-wave-per-node kernels take those).  Eight lanes per
+// node whatever its length: one wave instruction then serves eight nodes (the per-node bookkeeping
+// is ~180 VALU instructions per instruction stream, which bounds these kernels, not HBM) and still
+// moves whole 128-byte lines (8 lanes x 16 bytes per node).
+inline int small_shape(int V, int dtype, bool mis, int max_shape) {
+    const int epc = 16 / elem_size(dtype);
+    const int cover = mis ? (V + 2 * (epc - 1)) / epc : V / epc;  // chunks a row can touch (mis: at the worst offset)
+    constexpr int cap[5] = {8, 16, 32, 64, 128};
+    if (tuning_knob("RNNT_SMALL", 1) == 0) return -1;
+    for (int i = 0; i <= max_shape; ++i)
+        if (cover <= cap[i]) return i;
+    return -1;
+}
+#define FOR_EACH_SMALL(M) M(0, 8, 1, 8) M(1, 8, 2, 4) M(2, 8, 4, 2) M(3, 8, 8, 1) M(4, 8, 16, 1)
+#define FOR_EACH_SMALL_K3(M) M(0, 8, 1, 8) M(1, 8, 2, 4) M(2, 8, 4, 2) M(3, 8, 8, 1)
+constexpr int kSmallRowsPerWave[5] = {64, 32, 16, 8, 8};
+
 template <typename DT>
 rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens, const int *label_lens,
                        int V, int B, const Lattice &L, const rnntOptions &o) {
@@ -818,6 +1070,28 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     const long long rows = (long long)B * o.maxT * o.maxU;
     const int block = 256;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
+    const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
+    const int shape = small_shape(V, o.dtype, mis, 4);
+    if (shape >= 0) {
+        const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
+        const int sgrid = stream_grid(iters, block);
+        switch (shape) {
+#define CASE(I, LPR, NCH, NR)                                                                          \
+    case I:                                                                                            \
+        if (mis)                                                                                       \
+            hipLaunchKernelGGL((rnnt_k1_lse_small<DT, LPR, NCH, NR, true>), dim3(sgrid), dim3(block), 0, st,  \
+                               static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT,  \
+                               o.maxU, V, o.blank_label, rows, B);                                     \
+        else                                                                                           \
+            hipLaunchKernelGGL((rnnt_k1_lse_small<DT, LPR, NCH, NR, false>), dim3(sgrid), dim3(block), 0, st, \
+                               static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT,  \
+                               o.maxU, V, o.blank_label, rows, B);                                     \
+        break;
+            FOR_EACH_SMALL(CASE)
+#undef CASE
+        }
+        return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+    }
     const Tile t = pick_tile(acts, nullptr, V, o.dtype, 4);
     int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K1_GRID", 0);
@@ -863,6 +1137,26 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
     const long long rows = (long long)B * o.maxT * o.maxU;
     const int block = tuning_knob("RNNT_K3_BLOCK", 512);  // 8 nodes per workgroup: 3.14 -> 3.04 ms vs 256
     hipStream_t st = static_cast<hipStream_t>(o.stream);
+    const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
+    // 16 chunks per lane (rows of 64..128 chunks) cost K3 its occupancy: V=512 fp32 1.58 ms against 1.44 ms
+    // with one wave per node, so K3 stops one shape earlier than K1 (0.83 against 1.04 ms there)
+    const int shape = small_shape(V, o.dtype, mis, 3);
+    if (shape >= 0 && reinterpret_cast<uintptr_t>(acts) % 16 == reinterpret_cast<uintptr_t>(grads) % 16) {
+        const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
+        const int sgrid = stream_grid(iters, 256);
+        switch (shape) {
+#define CASE(I, LPR, NCH, NR)                                                                          \
+    case I:                                                                                            \
+        if (mis)                                                                                       \
+            hipLaunchKernelGGL((rnnt_k3_grad_small<DT, LPR, NCH, NR, true>), dim3(sgrid), dim3(256), 0, st, K3_ARGS, B);  \
+        else                                                                                           \
+            hipLaunchKernelGGL((rnnt_k3_grad_small<DT, LPR, NCH, NR, false>), dim3(sgrid), dim3(256), 0, st, K3_ARGS, B); \
+        break;
+            FOR_EACH_SMALL_K3(CASE)
+#undef CASE
+        }
+        return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+    }
     const Tile t = pick_tile(acts, grads, V, o.dtype, 1 << 20);
     int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K3_GRID", 0);
