@@ -88,10 +88,12 @@ def test_small_ragged_vs_oracle(B, T, U, V, seed, reduction):
     check_against_oracle(acts, labels, al, ll, reduction, go)
 
 
-@pytest.mark.parametrize("V", [5, 6, 7, 4234, 4232, 4100, 4352, 8200, 8196, 16384, 17408, 17412, 20000, 32768,
-                               65536, 70001])
+@pytest.mark.parametrize("V", [5, 6, 7, 29, 32, 33, 64, 100, 128, 250, 256, 257, 500, 512, 513, 1000, 1024, 4234,
+                               4232, 4100, 4352, 8200, 8196, 16384, 17408, 17412, 20000, 32768, 65536, 70001])
 def test_vocab_sizes_and_alignment(V):
-    # V % 4 != 0 -> element-granular fallback; 4352 = exactly 17 chunks/lane; 8200 -> two waves per
+    # up to 128 chunks per row (V <= 512 fp32): the small-row kernels, eight lanes per node with 1, 2, 4, 8 or
+    # 16 chunks per lane (K3 up to 8), several nodes of several utterances per wave instruction;
+    # 4352 = exactly 17 chunks/lane; 8200 -> two waves per
     # node in K1 and two segments in K3; 16384 -> four; from 17408 on K1 streams the row with one
     # workgroup per node (running max/sum); 20000 -> five K3 segments
     acts, labels, al, ll = make_case(2, 9, 4, V, seed=V, ragged=True)
@@ -99,7 +101,7 @@ def test_vocab_sizes_and_alignment(V):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("V", [64, 4232, 4234, 16384, 40000])
+@pytest.mark.parametrize("V", [64, 128, 250, 1000, 1024, 4232, 4234, 16384, 40000])
 def test_half_precision_logits(dtype, V):
     """bf16 / fp16 logits and grads with the fp32 lattice (BASELINE.json configs[4] numerics).
 
