@@ -1050,7 +1050,8 @@ inline int tuning_knob(const char *name, int dflt) {
 // node whatever its length: one wave instruction then serves eight nodes (the per-node bookkeeping
 // is ~180 VALU instructions per instruction stream, which bounds these kernels, not HBM) and still
 // moves whole 128-byte lines (8 lanes x 16 bytes per node).
-inline int small_shape(int V, int dtype, bool mis, int max_shape) {
+inline int small_shape(int V, int dtype, bool mis, int max_shape, int maxT) {
+    if (maxT >= (1 << 21)) return -1;  // small_div is exact below 2^22 (frame index + carry)
     const int epc = 16 / elem_size(dtype);
     const int cover = mis ? (V + 2 * (epc - 1)) / epc : V / epc;  // chunks a row can touch (mis: at the worst offset)
     constexpr int cap[5] = {8, 16, 32, 64, 128};
@@ -1071,7 +1072,7 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     const int block = 256;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
-    const int shape = small_shape(V, o.dtype, mis, 4);
+    const int shape = small_shape(V, o.dtype, mis, 4, o.maxT);
     if (shape >= 0) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, block);
@@ -1140,7 +1141,7 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
     const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
     // 16 chunks per lane (rows of 64..128 chunks) cost K3 its occupancy: V=512 fp32 1.58 ms against 1.44 ms
     // with one wave per node, so K3 stops one shape earlier than K1 (0.83 against 1.04 ms there)
-    const int shape = small_shape(V, o.dtype, mis, 3);
+    const int shape = small_shape(V, o.dtype, mis, 3, o.maxT);
     if (shape >= 0 && reinterpret_cast<uintptr_t>(acts) % 16 == reinterpret_cast<uintptr_t>(grads) % 16) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, 256);

@@ -192,3 +192,38 @@ def test_compute_rnnt_loss_upstream_shaped_call():
     bad = lib.compute_rnnt_loss(a.data_ptr(), grads.data_ptr(), lab.data_ptr(), lld.data_ptr(), ald.data_ptr(),
                                 40, 3, costs.data_ptr(), ws.data_ptr() + 4, opts)
     assert bad == 2
+
+
+def test_config4_sharded_equals_unsharded_bitwise_at_full_size():
+    """BASELINE config 4 (B=256, T=400, U=40, V=4232 fp32; 71 GB of logits) on ONE GPU: the whole batch in a
+    single call against its eight contiguous shards of 32 utterances run one after the other exactly as
+    the eight ranks of `bench.py --gpus 8` run them (per-utterance costs with reduction='none', local
+    gradient scaled by grad_out / B_global).  Costs and gradients must agree bit for bit; the all-reduce
+    of the zero-padded cost vector is exact, so this is the whole of the sharded path but the wire."""
+    import rnnt_amd
+
+    B, T, U, V, W = 256, 400, 40, 4232, 8
+    acts, labels, al, ll = device_case(B, T, U, V, ragged=False, seed=99)
+    lab_d, al_d, ll_d = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
+    go = 0.5
+    a = acts.requires_grad_(True)
+    costs = rnnt_amd.rnnt_loss(a, lab_d, al_d, ll_d, reduction="none")
+    mean = rnnt_amd.loss.reduce_costs(costs.detach(), "mean")
+    costs.backward(torch.full((B,), go / B, device=DEV))     # what 'mean' with grad_output = go does
+    full_grad = a.grad
+    a.grad = None
+    loss_mean, grad_mean = run(acts.detach(), labels, al, ll, "mean", go)
+    assert torch.equal(loss_mean, mean) and torch.equal(grad_mean, full_grad)
+    del grad_mean
+    gathered = torch.zeros(B, device=DEV)
+    for r in range(W):
+        lo, hi = rnnt_amd.shard_bounds(B, W, r)
+        s = acts.detach()[lo:hi].requires_grad_(True)
+        c = rnnt_amd.rnnt_loss(s, lab_d[lo:hi], al_d[lo:hi], ll_d[lo:hi], reduction="none")
+        c.backward(torch.full((hi - lo,), go * (1.0 / B), device=DEV))
+        assert torch.equal(s.grad, full_grad[lo:hi]), f"shard {r}: gradient differs from the unsharded one"
+        gathered[lo:hi] = c.detach()
+        del s, c
+    assert torch.equal(gathered, costs.detach())
+    assert torch.equal(rnnt_amd.loss.reduce_costs(gathered, "mean"), mean)
+    assert bool(torch.isfinite(mean).all())
