@@ -1001,9 +1001,11 @@ inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(p0) % 16, a1 = p1 ? reinterpret_cast<uintptr_t>(p1) % 16 : a0;
     if (a0 != a1) return t;  // logits and gradient rows must share their misalignment
     t.mis = V % epc != 0 || a0 != 0;
-    // chunks per lane if one wave took the whole row (+7: the 128-byte alignment shift; MIS: a row
-    // can straddle one more chunk)
-    const int need = ((V + epc - 1) / epc + (t.mis ? 1 : 0) + 7 + kWave - 1) / kWave;
+    // chunks per lane if one wave took the whole row (+7: the 128-byte alignment shift, which is zero
+    // when every row starts on a 128-byte boundary; MIS: a row can straddle one more chunk)
+    const bool lines = !t.mis && ((size_t)V * elem_size(dtype)) % 128 == 0 && reinterpret_cast<uintptr_t>(p0) % 128 == 0 &&
+                       (!p1 || reinterpret_cast<uintptr_t>(p1) % 128 == 0);
+    const int need = ((V + epc - 1) / epc + (t.mis ? 1 : 0) + (lines ? 0 : 7) + kWave - 1) / kWave;
     int nseg = (need + 16) / 17;
     if (max_seg == 4 && nseg == 3) nseg = 4;  // K1 splits a workgroup of 4 waves evenly
     if (nseg > max_seg) {
