@@ -149,6 +149,15 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
                                         void *grad_dec_proj, int B, int T, int U1, int H, rnntDtype_t dtype,
                                         void *workspace, void *stream);
 
+/*
+ * ---- greedy decoding --------------------------------------------------------
+ * out[r] = first index of the maximum of row r of x[rows, V] (a NaN counts as the maximum: torch.argmax's
+ * conventions).  Replaces the per-frame softmax -> argmax of the reference's greedy loop
+ * (/root/reference/src/rnnt/model.py:152-153; softmax is monotone, so the argmax of the logits is taken)
+ * for a whole window of frames in one launch; rnnt_amd/decode.py builds the loop of :145-165 on it.
+ */
+rnntStatus_t rnnt_row_argmax(const void *x, int rows, int V, rnntDtype_t dtype, int *out, void *stream);
+
 /* hipEvent helpers so a ctypes caller (bench.py) can time stages without a HIP binding. */
 rnntStatus_t rnnt_event_create(void **event);
 rnntStatus_t rnnt_event_destroy(void *event);

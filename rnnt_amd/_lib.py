@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
+    "rnnt_row_argmax",
     "rnnt_event_create",
     "rnnt_event_destroy",
     "rnnt_event_record",
@@ -117,6 +118,8 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_hidden_backward.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_joint_hidden_backward.restype = ctypes.c_int
+        lib.rnnt_row_argmax.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
+        lib.rnnt_row_argmax.restype = ctypes.c_int
         lib.rnnt_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         lib.rnnt_event_create.restype = ctypes.c_int
         lib.rnnt_event_destroy.argtypes = [ctypes.c_void_p]

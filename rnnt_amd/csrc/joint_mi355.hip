@@ -256,6 +256,46 @@ __global__ __launch_bounds__(256) void joint_dec_reduce(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row argmax for greedy decoding (the reference's per-frame
+// softmax -> argmax -> .item(), src/rnnt/model.py:151-154, over a window of frames at once).
+// One wave per row; the FIRST index of the maximum wins, a NaN counts as the maximum — the
+// conventions of torch.argmax.
+// ---------------------------------------------------------------------------------------------
+struct Best {
+    float v;   // NaN mapped to +inf
+    int nan;   // 1 if the value was a NaN (ranks above +inf)
+    int i;
+};
+__device__ __forceinline__ bool better(const Best &a, const Best &b) {  // a beats b
+    if (a.nan != b.nan) return a.nan > b.nan;
+    if (a.v != b.v) return a.v > b.v;
+    return a.i < b.i;
+}
+template <typename DT>
+__global__ __launch_bounds__(256) void row_argmax_kernel(const typename DT::elem *__restrict__ x, int rows, int V,
+                                                         int *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (r >= rows) return;
+    const typename DT::elem *row = x + (size_t)r * V;
+    Best best = {-INFINITY, 0, 0x7fffffff};
+    for (int v = lane; v < V; v += kWave) {
+        const float f = DT::to_float(row[v]);
+        const Best c = {f != f ? INFINITY : f, f != f ? 1 : 0, v};
+        if (better(c, best)) best = c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(best.v, off, kWave);
+        o.nan = __shfl_xor(best.nan, off, kWave);
+        o.i = __shfl_xor(best.i, off, kWave);
+        if (better(o, best)) best = o;
+    }
+    if (lane == 0) out[r] = best.i;
+}
+
 inline int frame_chunks(int T) { return (T + kTC - 1) / kTC; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -360,6 +400,27 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
             return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
+}
+
+rnntStatus_t rnnt_row_argmax(const void *x, int rows, int V, rnntDtype_t dtype, int *out, void *stream) {
+    if (x == nullptr || out == nullptr || rows < 1 || V < 1) return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (dtype) {
+        case RNNT_DTYPE_F32:
+            hipLaunchKernelGGL((row_argmax_kernel<F32>), grid, block, 0, st, static_cast<const float *>(x), rows, V, out);
+            break;
+        case RNNT_DTYPE_BF16:
+            hipLaunchKernelGGL((row_argmax_kernel<BF16>), grid, block, 0, st, static_cast<const __bf16 *>(x), rows, V,
+                               out);
+            break;
+        case RNNT_DTYPE_F16:
+            hipLaunchKernelGGL((row_argmax_kernel<F16>), grid, block, 0, st, static_cast<const _Float16 *>(x), rows, V,
+                               out);
+            break;
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 
 }  // extern "C"
