@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Greedy decoding of one utterance at the reference's sizes (T=400 frames, He=Hd=320, H=512, V=4232,
 1-layer LSTM decoder of 512 units as config/aishell.yaml): rnnt_amd.greedy_decode (windowed joint)
-against the reference's frame-by-frame loop (model.py:145-165, restated in oracle/decode_oracle.py)
+against the reference's frame-by-frame loop (model.py:145-165, restated below)
 with the same modules on the same MI355X.  Prints one JSON line."""
 import json
 import os
@@ -12,8 +12,26 @@ import torch
 import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch.nn.functional as F  # noqa: E402
+
 import rnnt_amd  # noqa: E402
-from oracle.decode_oracle import greedy_decode_reference  # noqa: E402  (the baseline being timed against)
+
+
+@torch.no_grad()
+def greedy_decode_reference(enc_state, length, decoder, joint_fn):
+    """The reference's formulation (model.py:145-165): one joint/softmax/argmax/.item() per frame."""
+    token_list, margin = [], float("inf")
+    dec_state, hidden = decoder(torch.zeros((1, 1), dtype=torch.long, device=enc_state.device))
+    for t in range(int(length)):
+        out = F.softmax(joint_fn(enc_state[t].view(-1), dec_state.view(-1)), dim=0)
+        top2 = torch.topk(out, 2).values
+        margin = min(margin, float(top2[0] - top2[1]))
+        pred = int(torch.argmax(out, dim=0).item())
+        if pred != 0:
+            token_list.append(pred)
+            dec_state, hidden = decoder(torch.full((1, 1), pred, dtype=torch.long, device=enc_state.device),
+                                        hidden=hidden)
+    return token_list, margin
 
 
 class Decoder(nn.Module):
