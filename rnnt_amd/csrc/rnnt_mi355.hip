@@ -1047,24 +1047,27 @@ inline int tuning_knob(const char *name, int dflt) {
 
 #define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)
 
-// Small rows: shape index into {LPR, NCH, NR} = {8,1,8} {8,2,4} {8,4,2} {8,8,1} {8,16,1}, or -1 when a
-// row can span more than 128 chunks (the one-wave-per-node kernels take those).  Eight lanes per
-// node whatever its length: one wave instruction then serves eight nodes (the per-node bookkeeping
-// is ~180 VALU instructions per instruction stream, which bounds these kernels, not HBM) and still
-// moves whole 128-byte lines (8 lanes x 16 bytes per node).
+// Small rows: shape index into {LPR, NCH, NR} = {4,1,8} {4,2,4} {8,2,4} {8,4,2} {8,8,1} {8,16,1}, or -1
+// when a row can span more than 128 chunks (the one-wave-per-node kernels take those).  Few lanes per
+// node whatever its length: one wave instruction then serves 8 or 16 nodes (the per-node bookkeeping
+// is ~180 VALU instructions per instruction stream, which bounds these kernels, not HBM).  With
+// 8 lanes a wave instruction still moves whole 128-byte lines per node; 4 lanes (64 bytes per node
+// and instruction) pay for rows up to 8 chunks (V=16: 1.29 -> 0.86 ms, V=29: 1.61 -> 1.36 ms at
+// 2.2e9 logits) but not for 16 (V=64: 1.83 -> 1.99 ms), and 2 lanes never did.
+constexpr int kSmallShapes = 6;
+constexpr int kSmallCap[kSmallShapes] = {4, 8, 16, 32, 64, 128};
+constexpr int kSmallRowsPerWave[kSmallShapes] = {128, 64, 32, 16, 8, 8};
 inline int small_shape(int V, int dtype, bool mis, int max_shape, int maxT) {
     if (maxT >= (1 << 21)) return -1;  // small_div is exact below 2^22 (frame index + carry)
     const int epc = 16 / elem_size(dtype);
     const int cover = mis ? (V + 2 * (epc - 1)) / epc : V / epc;  // chunks a row can touch (mis: at the worst offset)
-    constexpr int cap[5] = {8, 16, 32, 64, 128};
     if (tuning_knob("RNNT_SMALL", 1) == 0) return -1;
     for (int i = 0; i <= max_shape; ++i)
-        if (cover <= cap[i]) return i;
+        if (cover <= kSmallCap[i]) return i;
     return -1;
 }
-#define FOR_EACH_SMALL(M) M(0, 8, 1, 8) M(1, 8, 2, 4) M(2, 8, 4, 2) M(3, 8, 8, 1) M(4, 8, 16, 1)
-#define FOR_EACH_SMALL_K3(M) M(0, 8, 1, 8) M(1, 8, 2, 4) M(2, 8, 4, 2) M(3, 8, 8, 1)
-constexpr int kSmallRowsPerWave[5] = {64, 32, 16, 8, 8};
+#define FOR_EACH_SMALL(M) M(0, 4, 1, 8) M(1, 4, 2, 4) M(2, 8, 2, 4) M(3, 8, 4, 2) M(4, 8, 8, 1) M(5, 8, 16, 1)
+#define FOR_EACH_SMALL_K3(M) M(0, 4, 1, 8) M(1, 4, 2, 4) M(2, 8, 2, 4) M(3, 8, 4, 2) M(4, 8, 8, 1)
 
 template <typename DT>
 rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens, const int *label_lens,
@@ -1074,7 +1077,7 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     const int block = 256;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
-    const int shape = small_shape(V, o.dtype, mis, 4, o.maxT);
+    const int shape = small_shape(V, o.dtype, mis, 5, o.maxT);
     if (shape >= 0) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, block);
@@ -1143,7 +1146,7 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
     const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
     // 16 chunks per lane (rows of 64..128 chunks) cost K3 its occupancy: V=512 fp32 1.58 ms against 1.44 ms
     // with one wave per node, so K3 stops one shape earlier than K1 (0.83 against 1.04 ms there)
-    const int shape = small_shape(V, o.dtype, mis, 3, o.maxT);
+    const int shape = small_shape(V, o.dtype, mis, 4, o.maxT);
     if (shape >= 0 && reinterpret_cast<uintptr_t>(acts) % 16 == reinterpret_cast<uintptr_t>(grads) % 16) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, 256);
