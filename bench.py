@@ -112,8 +112,8 @@ def main():
                     help="with --workload custom: B,T,U,V,dtype[,ragged]  e.g. 64,400,40,128,f32 (tuning sweeps; "
                          "not a BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-b", type=int, default=16)
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-sample-b", type=int, default=32)
+    ap.add_argument("--cpu-reps", type=int, default=6)
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded harness (RCCL all-reduce of costs) even with one rank")
     ap.add_argument("--no-check-lengths", action="store_true",
