@@ -76,6 +76,8 @@ def cpu_baseline(w, sample_B, reps):
     import oracle  # test infrastructure: used here only as the reported CPU baseline
 
     oracle.build()
+    # bounded sample: at most ~2.5e9 logits (10 GB of fp32 logits + as much for the gradient) on the host
+    sample_B = max(1, min(sample_B, int(2.5e9 // (w["T"] * (w["U"] + 1) * w["V"]))))
     B, T, U, V = sample_B, w["T"], w["U"], w["V"]
     g = torch.Generator().manual_seed(1234)
     acts = torch.empty((B, T, U + 1, V), dtype=torch.float32).normal_(0, 1, generator=g).numpy()
