@@ -23,10 +23,11 @@
  * with an OpenMP `parallel for` over the minibatch (one utterance per thread).
  *
  * PARITY UNPINNED: the reference holds no tests, golden vectors or fixtures
- * for this path.  The only anchor is the B1·T2·U2·V5
- * known-answer vector recalled from the upstream package's public unit test
- * (cost 4.4956668), which tests/test_oracle.py checks together with a float64
- * dynamic programme, autograd through it, and brute-force path enumeration.
+ * for this path.  The anchors are two known-answer vectors
+ * recalled from the upstream package's public unit tests (B1·T2·U2·V5, cost
+ * 4.4956668; B2·T4·U2·V3, costs 4.2806528590890736 / 3.9384369822503591), which
+ * tests/test_oracle.py checks together with a float64 dynamic programme,
+ * autograd through it, and brute-force path enumeration.
  */
 #include <math.h>
 #include <stdlib.h>

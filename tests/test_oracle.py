@@ -179,3 +179,16 @@ def test_invalid_arguments_are_rejected():
     bad[0, 0] = 5
     with pytest.raises(ValueError):
         oracle.rnnt_loss_c(a, bad, al, ll)              # label >= V
+
+
+def test_oracle_under_sanitizers():
+    """the oracle's C source, instrumented with AddressSanitizer and UBSan (host code only),
+    runs both known-answer vectors and a ragged batch whose padding holds NaN (oracle/selftest.c)."""
+    import subprocess
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "selftest_asan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0", OMP_NUM_THREADS="3")
+    out = subprocess.run([os.path.join(here, "selftest_asan")], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "oracle selftest ok" in out.stdout
