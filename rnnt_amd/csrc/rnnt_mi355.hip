@@ -230,12 +230,12 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Small rows (up to 256 chunks, i.e. V <= ~1000 fp32 / ~2000 16-bit; char and small word-piece
-// vocabularies).  One wave per node is latency-bound there: a wave has one short row in flight and
+// Small rows (up to 128 chunks of 16 bytes, i.e. V <= 512 fp32 / 1024 16-bit; char and small
+// word-piece vocabularies).  One wave per node is latency-bound there: a wave has one short row in flight and
 // spends ~7k cycles on the dependent chain lengths -> row -> reductions -> store.  These variants
 // give a wave G*NR consecutive nodes per iteration: LPR lanes per node (G = 64/LPR nodes side by
-// side, NCH chunks per lane) times NR nodes per lane group, all loads issued before the first reduction.  Rows may
-// start at any element offset of a 16-byte chunk (V = 29: 116-byte rows); boundary chunks are
+// side, NCH chunks per lane) times NR nodes per lane group, all loads issued before the first
+// reduction.  Rows may start at any element offset of a 16-byte chunk (V = 29: 116-byte rows); boundary chunks are
 // masked on the way in and stored by element on the way out, exactly as in the MIS variants above.
 // ---------------------------------------------------------------------------------------------
 struct SmallRow {
