@@ -76,14 +76,20 @@ __device__ __forceinline__ u32x4 mask_outside_row(const u32x4 &raw, int first, i
 }
 template <typename DT>
 __device__ __forceinline__ void store_inside_row(const u32x4 &v, u32x4 *p, int first, int V) {
-    // element-wise stores of the part of a boundary chunk that belongs to this row
-    typedef typename DT::elem E;
-    E tmp[DT::EPC];
-    __builtin_memcpy(tmp, &v, 16);
-    E *o = reinterpret_cast<E *>(p);
+    // element-wise stores of the part of a boundary chunk that belongs to this row (plain integer
+    // moves: going through an array of the element type made hipcc spill hundreds of registers for fp16)
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(typename DT::elem) == 4) {
+        unsigned *o = reinterpret_cast<unsigned *>(p);
 #pragma unroll
-    for (int j = 0; j < DT::EPC; ++j)
-        if ((unsigned)(first + j) < (unsigned)V) o[j] = tmp[j];
+        for (int j = 0; j < 4; ++j)
+            if ((unsigned)(first + j) < (unsigned)V) o[j] = w[j];
+    } else {
+        unsigned short *o = reinterpret_cast<unsigned short *>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((unsigned)(first + j) < (unsigned)V) o[j] = (unsigned short)(w[j >> 1] >> (16 * (j & 1)));
+    }
 }
 
 struct Lattice {      // device pointers into the workspace
@@ -110,16 +116,30 @@ struct Lattice {      // device pointers into the workspace
 // roughly the same bytes in flight per CU.
 // epc = elements per 16-byte chunk.  16-bit logits carry twice the VALU work per byte: K1 then wants
 // one more wave per SIMD (config 5: 18.8 -> 17.9 ms); K3 still runs best at 2 (38.2 vs 40.0 at 3).
-[[maybe_unused]] constexpr int k1_waves(int nch, int epc) {
-    return nch >= 16 ? (epc > 4 ? 4 : 3) : nch >= 12 ? 4 : nch >= 8 ? 6 : 8;
+// The attribute below pins BOTH bounds (min = max = N), i.e. it also limits the kernel to 512/N
+// VGPRs: N must not exceed what the instantiation reaches without spilling (a cap of 8 on a kernel
+// that wants 91 registers costs 179 spills; fp16 converts need more registers than bf16 shifts).
+// `cvt` = the element type unpacks through conversions (fp16).  The spill-free bounds below come from
+// the -Rpass-analysis=kernel-resource-usage report of a build without the attribute
+// (`make -C rnnt_amd/csrc resources`); raising N beyond them makes hipcc spill, lowering some of
+// them (K3 NCH 6/8 to 4/3) flips its scheduler into a 256-VGPR schedule that runs 30x slower.
+[[maybe_unused]] constexpr int k1_waves(int nch, int epc, bool mis, int wpr, bool cvt) {
+    int w = nch >= 16 ? (epc > 4 ? 4 : 3) : nch >= 12 ? 4 : nch >= 8 ? 6 : 8;
+    if (mis && epc == 4 && nch <= 4 && w > 5) w = 5;  // fp32 boundary masks: 91 VGPRs (V=601: K1 17.6 -> 2.0 ms)
+    if (mis && cvt && nch >= 16) w = wpr > 1 ? 2 : 3;
+    if (mis && cvt && nch >= 12 && nch < 16 && wpr > 1) w = 3;
+    return w;
 }
 [[maybe_unused]] constexpr int k3_waves(int nch, int epc) {
-    (void)epc;
-    return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 6 : 8;
+    // NCH = 4: 16-bit logits want 94 VGPRs (bf16 V=1500: 1.84 -> 1.27 ms at 5 waves); fp32 runs best at 8
+    // with its 4 spilled registers (V=600: 1.71 ms against 2.60 at 5 and 2.04 at 6)
+    return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 5 : nch >= 4 ? (epc > 4 ? 5 : 8) : 8;
 }
+template <typename DT>
+constexpr bool kCvtUnpack = sizeof(typename DT::elem) == 2 && !__is_same(typename DT::elem, __bf16);
 
 template <typename DT, int NCH, int WPR, bool MIS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC), k1_waves(NCH, DT::EPC))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>), k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>))))
 void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ labels,
                                                    const int *__restrict__ act_lens,

@@ -1,0 +1,35 @@
+"""Build-time guard (no GPU): no reachable kernel instantiation may spill registers to scratch.
+
+The occupancy attribute on K1/K3 pins the VGPR budget (512 / waves per SIMD); a bound chosen too
+high for an instantiation makes hipcc spill — K1<fp32, NCH=4, misaligned> once ran 17.6 ms instead
+of 2.0 ms that way and K3<fp16, NCH=8, misaligned> 70 ms instead of 1.3 ms, with all parity tests
+green.  This test reads hipcc's own resource report for the gfx950 code objects."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rnnt_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+         "-Rpass-analysis=kernel-resource-usage", "-c"]
+MAX_SPILLED_VGPRS = 8
+
+
+@pytest.mark.parametrize("src", ["rnnt_mi355.hip", "joint_mi355.hip"])
+def test_no_reachable_kernel_spills(src, tmp_path):
+    out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-o", str(tmp_path / "o.o"), os.path.join(CSRC, src)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", out.stderr)]
+    assert names and len(names) == len(spills)
+    bad = []
+    for name, spilled in zip(names, spills):
+        m = re.search(r"rnnt_k1_lseIN17rnnt_mi355_detail\d\w+?ELi(\d+)ELi(\d)E", name)
+        if m and int(m.group(2)) > 1 and int(m.group(1)) < 12:
+            continue  # K1 with several waves per node is only launched with 12+ chunks per lane (pick_tile)
+        if spilled > MAX_SPILLED_VGPRS:
+            bad.append((name, spilled))
+    assert not bad, bad
