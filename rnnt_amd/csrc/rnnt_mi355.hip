@@ -56,9 +56,26 @@ __device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US
     return ((size_t)b * (ND + 1) + (size_t)(t + u)) * US + u;  // +1: K2's junk row
 }
 
+// Word 3 of a raw (stride 0, byte-offset) buffer descriptor on gfx90a/gfx942/gfx950: 32-bit data
+// format, offsets checked against num_records; and the `nt` bit of a buffer load's cache policy.
+constexpr int kRawBufferFlags = 0x00020000;
+constexpr int kBufferNontemporal = 2;
+
 // 16-byte chunks between the previous 128-byte boundary and p
 __device__ __forceinline__ int row_misalign(const void *p) {
     return (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);
+}
+
+// Previous 16-byte boundary at or below p.  Pointer arithmetic, not an integer mask: a pointer
+// rebuilt from a masked integer loses its address space and every access through it becomes a
+// flat_load / flat_store the compiler waits on one at a time.
+template <typename T>
+__device__ __forceinline__ const u32x4 *align_down16(const T *p) {
+    return reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p) - (reinterpret_cast<uintptr_t>(p) & 15));
+}
+template <typename T>
+__device__ __forceinline__ u32x4 *align_down16(T *p) {
+    return reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(p) - (reinterpret_cast<uintptr_t>(p) & 15));
 }
 
 // Rows that are not 16-byte aligned (V*elem % 16 != 0, e.g. the reference's V = 4234 and 5455):
@@ -169,17 +186,28 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         const typename DT::elem *row = acts + (size_t)(valid ? r : 0) * (size_t)V;
         const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
         const int shift = MIS ? (int)((addr & 15) / sizeof(typename DT::elem)) : 0;  // previous row's elements in chunk 0
-        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (addr & ~(uintptr_t)15) : addr);
+        const u32x4 *row4 = MIS ? align_down16(row) : reinterpret_cast<const u32x4 *>(row);
         const int nchunks = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
         // Chunk index of lane 0 is shifted back so that every wave-instruction covers one
         // 128-byte-aligned KiB of memory whatever the row's own alignment (rows are only 16-byte
         // aligned: V*elem need not be a multiple of 128).
         const int c0 = seg * NCH * kWave + lane - row_misalign(row4);
         u32x4 raw[NCH];
+        // Buffer loads bounded to the row: lanes before its first or past its last chunk get zeros
+        // back without a memory request and without a branch.  (With each load under its own lane
+        // mask hipcc merged it with the max pass below and waited for one load before issuing the
+        // next in the fp16 and in every misaligned instantiation: 3.6 TB/s instead of 5.4.)
+        // The descriptor has to sit in SGPRs; the row is the same for the whole wave.
+        {
+            const uintptr_t a4 = reinterpret_cast<uintptr_t>(row4);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a4);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a4 >> 32));
+            const int bytes = __builtin_amdgcn_readfirstlane(valid ? nchunks * 16 : 0);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), (short)0, bytes, kRawBufferFlags);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int idx = c0 + k * kWave;
-            if (valid && idx >= 0 && idx < nchunks) raw[k] = __builtin_nontemporal_load(row4 + idx);
+            for (int k = 0; k < NCH; ++k)
+                raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c0 + k * kWave) * 16, 0, kBufferNontemporal);
         }
         if (MIS) {
 #pragma unroll
@@ -310,16 +338,17 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
         u32x4 raw[NR][NCH];
         int first[NR];   // row index of element 0 of this lane's chunk 0 (negative in the boundary chunk)
         int nchunks[NR];
-        const typename DT::elem *rowp[NR];
+        size_t rowoff[NR];  // (an array of row pointers would come back as flat pointers)
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             const int o = n * G + grp;
             row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
             const long long r = row[n].valid ? r0 + o : 0;  // skipped nodes read (and ignore) row 0
-            rowp[n] = acts + (size_t)r * (size_t)V;
-            const uintptr_t addr = reinterpret_cast<uintptr_t>(rowp[n]);
+            rowoff[n] = (size_t)r * (size_t)V;
+            const typename DT::elem *rowp = acts + rowoff[n];
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(rowp);
             const int shift = MIS ? (int)((addr & 15) / sizeof(typename DT::elem)) : 0;
-            const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (addr & ~(uintptr_t)15) : addr);
+            const u32x4 *row4 = MIS ? align_down16(rowp) : reinterpret_cast<const u32x4 *>(rowp);
             nchunks[n] = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
             first[n] = sub * EPC - shift;
 #pragma unroll
@@ -336,8 +365,8 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
             xy[n] = 0.0f;
             if (sub == 0 && row[n].valid) {
                 const int y = row[n].u < row[n].Ub ? labels[(size_t)row[n].b * (U1 - 1) + row[n].u] : blank;
-                xb[n] = DT::to_float(rowp[n][blank]);
-                xy[n] = (y >= 0 && y < V) ? DT::to_float(rowp[n][y]) : __builtin_nanf("");
+                xb[n] = DT::to_float(acts[rowoff[n] + blank]);
+                xy[n] = (y >= 0 && y < V) ? DT::to_float(acts[rowoff[n] + y]) : __builtin_nanf("");
             }
         }
         float m[NR], s[NR];
@@ -793,9 +822,9 @@ void rnnt_k3_grad(
         const int Ub = label_lens[c.b];
         // MIS: rows are not 16-byte aligned (host guarantees acts and grads share the misalignment);
         // `shift` elements of the previous row sit in chunk 0, see mask_outside_row
-        const uintptr_t oaddr = reinterpret_cast<uintptr_t>(grads + (size_t)r * (size_t)V);
-        const int shift = MIS ? (int)((oaddr & 15) / sizeof(typename DT::elem)) : 0;
-        u32x4 *out4 = reinterpret_cast<u32x4 *>(MIS ? (oaddr & ~(uintptr_t)15) : oaddr);
+        typename DT::elem *orow = grads + (size_t)r * (size_t)V;
+        const int shift = MIS ? (int)((reinterpret_cast<uintptr_t>(orow) & 15) / sizeof(typename DT::elem)) : 0;
+        u32x4 *out4 = MIS ? align_down16(orow) : reinterpret_cast<u32x4 *>(orow);
         const int nchunks = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
         // lane 0 shifted back so each wave-instruction covers a 128-byte-aligned KiB (see K1)
         const int c0 = (int)(wi - r * nseg) * NCH * kWave + lane - row_misalign(out4);
@@ -813,8 +842,8 @@ void rnnt_k3_grad(
             }
             continue;
         }
-        const uintptr_t iaddr = reinterpret_cast<uintptr_t>(acts + (size_t)r * (size_t)V);
-        const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (iaddr & ~(uintptr_t)15) : iaddr);
+        const typename DT::elem *irow = acts + (size_t)r * (size_t)V;
+        const u32x4 *row4 = MIS ? align_down16(irow) : reinterpret_cast<const u32x4 *>(irow);
         u32x4 raw[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -878,11 +907,12 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad_small(
             row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
             const long long r = row[n].exists ? r0 + o : 0;
             // host guarantees acts and grads share their misalignment, so one shift serves both
-            const uintptr_t oaddr = reinterpret_cast<uintptr_t>(grads + (size_t)r * (size_t)V);
-            const uintptr_t iaddr = reinterpret_cast<uintptr_t>(acts + (size_t)(row[n].valid ? r : 0) * (size_t)V);
-            const int shift = MIS ? (int)((oaddr & 15) / sizeof(E)) : 0;
-            out4[n] = reinterpret_cast<u32x4 *>(MIS ? (oaddr & ~(uintptr_t)15) : oaddr);
-            const u32x4 *row4 = reinterpret_cast<const u32x4 *>(MIS ? (iaddr & ~(uintptr_t)15) : iaddr);
+            E *orow = grads + (size_t)r * (size_t)V;
+            const E *irow = acts + (size_t)(row[n].valid ? r : 0) * (size_t)V;
+            const uintptr_t iaddr = reinterpret_cast<uintptr_t>(irow);
+            const int shift = MIS ? (int)((reinterpret_cast<uintptr_t>(orow) & 15) / sizeof(E)) : 0;
+            out4[n] = MIS ? align_down16(orow) : reinterpret_cast<u32x4 *>(orow);
+            const u32x4 *row4 = MIS ? align_down16(irow) : reinterpret_cast<const u32x4 *>(irow);
             nchunks[n] = MIS ? (shift + V + EPC - 1) / EPC : V / EPC;
             first[n] = sub * EPC - shift;
             // = nchunks unless row 0 stands in for a padding node
