@@ -61,6 +61,15 @@ __device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US
 constexpr int kRawBufferFlags = 0x00020000;
 constexpr int kBufferNontemporal = 2;
 
+// Descriptor of `bytes` bytes at p; both must be the same in every lane of the wave (it lives in SGPRs).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(const void *p, int bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), (short)0,
+                                             __builtin_amdgcn_readfirstlane(bytes), kRawBufferFlags);
+}
+
 // 16-byte chunks between the previous 128-byte boundary and p
 __device__ __forceinline__ int row_misalign(const void *p) {
     return (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);
@@ -155,6 +164,15 @@ struct Lattice {      // device pointers into the workspace
 template <typename DT>
 constexpr bool kCvtUnpack = sizeof(typename DT::elem) == 2 && !__is_same(typename DT::elem, __bf16);
 
+// fp16 only: the conversions of the first pass otherwise get scheduled (or merged, when both run
+// under the same lane mask) right behind each load, and every load is waited for before the next
+// one is issued.  An empty asm that names all chunks keeps the loads together.
+template <int N>
+__device__ __forceinline__ void loads_issued(u32x4 (&raw)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));
+}
+
 template <typename DT, int NCH, int WPR, bool MIS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>), k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>))))
 void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
@@ -199,12 +217,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         // next in the fp16 and in every misaligned instantiation: 3.6 TB/s instead of 5.4.)
         // The descriptor has to sit in SGPRs; the row is the same for the whole wave.
         {
-            const uintptr_t a4 = reinterpret_cast<uintptr_t>(row4);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a4);
-            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a4 >> 32));
-            const int bytes = __builtin_amdgcn_readfirstlane(valid ? nchunks * 16 : 0);
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), (short)0, bytes, kRawBufferFlags);
+            const __amdgpu_buffer_rsrc_t rsrc = row_buffer(row4, valid ? nchunks * 16 : 0);
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
                 raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c0 + k * kWave) * 16, 0, kBufferNontemporal);
@@ -296,24 +309,34 @@ struct SmallRow {
 // (x + 0.5) * (1/d) truncated is x / d exactly while x < 2^22 (the half keeps the product away from
 // every integer by 0.5/d, far more than the fp32 rounding of it): maxT and maxU are far below that
 __device__ __forceinline__ int small_div(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
-__device__ __forceinline__ SmallRow small_row(const RowCoord &c0, int o, long long r0, long long total_rows,
-                                              const int *__restrict__ act_lens,
-                                              const int *__restrict__ label_lens, int maxT, int U1, int B,
-                                              float inv_T, float inv_U1) {
-    SmallRow s;
-    const int uu = c0.u + o;
-    const int dt = small_div(uu, inv_U1);
-    s.u = uu - dt * U1;
-    const int tt = c0.t + dt;
-    const int db = small_div(tt, inv_T);
-    s.t = tt - db * maxT;
-    s.b = c0.b + db;
-    s.exists = r0 + o < total_rows;
-    const int bb = s.b < B ? s.b : B - 1;
-    s.Tb = act_lens[bb];
-    s.Ub = label_lens[bb];
-    s.valid = s.exists && lens_ok(s.Tb, s.Ub, maxT, U1) && s.t < s.Tb && s.u <= s.Ub;
-    return s;
+// The NR nodes of one lane group.  All length loads are issued before the first is used (loads
+// return in order: interleaved with their uses they cost one memory round trip per node).
+template <int NR, int G>
+__device__ __forceinline__ void small_rows(SmallRow (&s)[NR], const RowCoord &c0, int grp, long long r0,
+                                           long long total_rows, const int *__restrict__ act_lens,
+                                           const int *__restrict__ label_lens, int maxT, int U1, int B,
+                                           float inv_T, float inv_U1) {
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int o = n * G + grp;
+        const int uu = c0.u + o;
+        const int dt = small_div(uu, inv_U1);
+        s[n].u = uu - dt * U1;
+        const int tt = c0.t + dt;
+        const int db = small_div(tt, inv_T);
+        s[n].t = tt - db * maxT;
+        s[n].b = c0.b + db;
+        s[n].exists = r0 + o < total_rows;
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int bb = s[n].b < B ? s[n].b : B - 1;
+        s[n].Tb = act_lens[bb];
+        s[n].Ub = label_lens[bb];
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+        s[n].valid = s[n].exists && lens_ok(s[n].Tb, s[n].Ub, maxT, U1) && s[n].t < s[n].Tb && s[n].u <= s[n].Ub;
 }
 
 template <typename DT, int LPR, int NCH, int NR, bool MIS>
@@ -334,16 +357,28 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
     for (long long it = wave0; it < niter; it += nwaves) {  // host launches one wave per iteration
         const long long r0 = it * RPW;
         const RowCoord c0 = decode_row(r0, maxT, U1);
+        // Loads return in order, so each phase below issues its loads for all NR nodes before anything
+        // waits for them: lengths -> labels and rows -> the two gathered logits (three round trips per
+        // iteration; interleaved per node it was one round trip per node).
         SmallRow row[NR];
+        small_rows<NR, G>(row, c0, grp, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
+        int y[NR];
+        if (U1 > 1) {  // (labels may be an empty tensor otherwise)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const bool emit = row[n].valid && row[n].u < row[n].Ub;
+                y[n] = labels[emit ? (size_t)row[n].b * (U1 - 1) + row[n].u : 0];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) y[n] = (U1 > 1 && row[n].valid && row[n].u < row[n].Ub) ? y[n] : blank;
         u32x4 raw[NR][NCH];
         int first[NR];   // row index of element 0 of this lane's chunk 0 (negative in the boundary chunk)
         int nchunks[NR];
         size_t rowoff[NR];  // (an array of row pointers would come back as flat pointers)
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-            const int o = n * G + grp;
-            row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
-            const long long r = row[n].valid ? r0 + o : 0;  // skipped nodes read (and ignore) row 0
+            const long long r = row[n].valid ? r0 + (n * G + grp) : 0;  // skipped nodes read (and ignore) row 0
             rowoff[n] = (size_t)r * (size_t)V;
             const typename DT::elem *rowp = acts + rowoff[n];
             const uintptr_t addr = reinterpret_cast<uintptr_t>(rowp);
@@ -357,16 +392,18 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
                 raw[n][k] = __builtin_nontemporal_load(row4 + (idx < nchunks[n] ? idx : nchunks[n] - 1));
             }
         }
-        // the two gathered logits and the label, by the leading lane of each group
+        // the two gathered logits (same address in every lane of a group; a label outside [0,V) is
+        // the caller's error and yields NaN, as in rnnt_k1_lse)
         float xb[NR], xy[NR];
 #pragma unroll
-        for (int n = 0; n < NR; ++n) {
-            xb[n] = 0.0f;
-            xy[n] = 0.0f;
-            if (sub == 0 && row[n].valid) {
-                const int y = row[n].u < row[n].Ub ? labels[(size_t)row[n].b * (U1 - 1) + row[n].u] : blank;
+        for (int n = 0; n < NR; ++n) xb[n] = xy[n] = 0.0f;
+        if (sub == 0) {  // one branch around all of them: the leading lane of each group stores the result
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const bool y_ok = y[n] >= 0 && y[n] < V;
                 xb[n] = DT::to_float(acts[rowoff[n] + blank]);
-                xy[n] = (y >= 0 && y < V) ? DT::to_float(acts[rowoff[n] + y]) : __builtin_nanf("");
+                xy[n] = DT::to_float(acts[rowoff[n] + (y_ok ? y[n] : 0)]);
+                xy[n] = y_ok ? xy[n] : __builtin_nanf("");
             }
         }
         float m[NR], s[NR];
@@ -455,6 +492,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
                 const int idx = base + k * 256;
                 raw[k] = __builtin_nontemporal_load(row4 + (idx < nchunks ? idx : nchunks - 1));
             }
+            if (kCvtUnpack<DT>) loads_issued(raw);
             float bm = -INFINITY;
 #pragma unroll
             for (int k = 0; k < UNR; ++k) {
@@ -749,6 +787,44 @@ __device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &
     return n;
 }
 
+// The same in two steps for kernels that handle several nodes per lane: every value node_coef reads,
+// loaded unconditionally (nothing here depends on another load), then the arithmetic.
+struct NodeIn {
+    float llb, a, go, beta_t, beta_u;
+    float2 lp, ml;
+};
+__device__ __forceinline__ NodeIn node_in(const Lattice &L, const RowCoord &c, bool emit,
+                                          const float *__restrict__ grad_out, int grad_out_stride) {
+    const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+    NodeIn in;
+    in.llb = L.ll[c.b];
+    in.a = L.alpha[o];
+    in.lp = L.lp[o];
+    in.ml = L.ml[o];
+    in.go = grad_out ? grad_out[(size_t)c.b * grad_out_stride] : 1.0f;
+    in.beta_t = L.beta[o + L.US];                 // next diagonal (the last one is followed by K2's junk row)
+    in.beta_u = L.beta[o + L.US + (emit ? 1 : 0)];  // column u+1 only where it exists
+    return in;
+}
+__device__ __forceinline__ NodeCoef node_coef_from(const NodeIn &in, int t, int u, int Tb, int Ub, int y,
+                                                   float grad_scale) {
+    const float scale = grad_scale * in.go;
+    float bk = 0.0f, yk = 0.0f;
+    if (t < Tb - 1)
+        bk = __expf(in.a + in.beta_t + in.lp.x - in.llb);
+    else if (u == Ub)
+        bk = __expf(in.a + in.lp.x - in.llb);
+    if (u < Ub) yk = __expf(in.a + in.beta_u + in.lp.y - in.llb);
+    NodeCoef n;
+    n.y = u < Ub ? y : -1;
+    n.m = in.ml.x;
+    n.l = in.ml.y;
+    n.sa = scale * (bk + yk);
+    n.sbk = scale * bk;
+    n.syk = scale * yk;
+    return n;
+}
+
 // One 16-byte chunk of a node's row.  The two sparse corrections (blank and label logit) touch one
 // lane of one wave-instruction each; `hit_b` / `hit_y` are wave-uniform ("this instruction holds
 // it"), so the element-wise part stays at sub, fma, exp2, mul per logit — K3 at two waves per SIMD
@@ -845,10 +921,20 @@ void rnnt_k3_grad(
         const typename DT::elem *irow = acts + (size_t)r * (size_t)V;
         const u32x4 *row4 = MIS ? align_down16(irow) : reinterpret_cast<const u32x4 *>(irow);
         u32x4 raw[NCH];
+        if (NCH <= 6) {
+            // short rows: bounded buffer loads as in K1 (fp16 with 4 chunks per lane otherwise waits
+            // for each load before issuing the next: V = 1000, K3 2.46 -> 1.85 ms).  From 8 chunks
+            // per lane up the lane-masked loads below measure the same or better (V = 8192: +4.5 %).
+            const __amdgpu_buffer_rsrc_t rsrc = row_buffer(row4, nchunks * 16);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int idx = c0 + k * kWave;
-            if (idx >= 0 && idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
+            for (int k = 0; k < NCH; ++k)
+                raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c0 + k * kWave) * 16, 0, NTL ? kBufferNontemporal : 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int idx = c0 + k * kWave;
+                if (idx >= 0 && idx < nchunks) raw[k] = ld16<NTL>(row4 + idx);
+            }
         }
         const NodeCoef n = node_coef(L, c, Tb, Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
         const float nl2 = -n.l * kLog2e;  // softmax_v = 2^((x_v - m)*log2e - l*log2e)
@@ -897,14 +983,33 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad_small(
     for (long long it = wave0; it < niter; it += nwaves) {
         const long long r0 = it * RPW;
         const RowCoord c0 = decode_row(r0, maxT, U1);
+        // Phases as in rnnt_k1_lse_small: lengths -> lattice values and rows -> arithmetic, each
+        // phase's loads issued for all NR nodes before anything waits for them.
         SmallRow row[NR];
+        small_rows<NR, G>(row, c0, grp, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
+        NodeIn in[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            RowCoord c;  // padding nodes read (and ignore) node (0,0,0)
+            c.b = row[n].valid ? row[n].b : 0;
+            c.t = row[n].valid ? row[n].t : 0;
+            c.u = row[n].valid ? row[n].u : 0;
+            in[n] = node_in(L, c, row[n].valid && row[n].u < row[n].Ub, grad_out, grad_out_stride);
+        }
+        int y[NR];
+        if (U1 > 1) {  // (labels may be an empty tensor otherwise)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const bool emit = row[n].valid && row[n].u < row[n].Ub;
+                y[n] = labels[emit ? (size_t)row[n].b * (U1 - 1) + row[n].u : 0];
+            }
+        }
         u32x4 raw[NR][NCH];
         int first[NR], nchunks[NR];
         u32x4 *out4[NR];
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             const int o = n * G + grp;
-            row[n] = small_row(c0, o, r0, total_rows, act_lens, label_lens, maxT, U1, B, inv_T, inv_U1);
             const long long r = row[n].exists ? r0 + o : 0;
             // host guarantees acts and grads share their misalignment, so one shift serves both
             E *orow = grads + (size_t)r * (size_t)V;
@@ -926,13 +1031,9 @@ __global__ __launch_bounds__(256) void rnnt_k3_grad_small(
         NodeCoef coef[NR];
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-            if (row[n].valid) {
-                RowCoord c;
-                c.b = row[n].b;
-                c.t = row[n].t;
-                c.u = row[n].u;
-                coef[n] = node_coef(L, c, row[n].Tb, row[n].Ub, labels, U1, grad_out, grad_out_stride, grad_scale);
-            } else {
+            const bool emit = U1 > 1 && row[n].valid && row[n].u < row[n].Ub;
+            coef[n] = node_coef_from(in[n], row[n].t, row[n].u, row[n].Tb, row[n].Ub, emit ? y[n] : -1, grad_scale);
+            if (!row[n].valid) {
                 coef[n].sa = coef[n].sbk = coef[n].syk = 0.0f;
                 coef[n].m = coef[n].l = 0.0f;
                 coef[n].y = -1;
