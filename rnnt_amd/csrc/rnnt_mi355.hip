@@ -151,15 +151,16 @@ struct Lattice {      // device pointers into the workspace
 // them (K3 NCH 6/8 to 4/3) flips its scheduler into a 256-VGPR schedule that runs 30x slower.
 [[maybe_unused]] constexpr int k1_waves(int nch, int epc, bool mis, int wpr, bool cvt) {
     int w = nch >= 16 ? (epc > 4 ? 4 : 3) : nch >= 12 ? 4 : nch >= 8 ? 6 : 8;
-    if (mis && epc == 4 && nch <= 4 && w > 5) w = 5;  // fp32 boundary masks: 91 VGPRs (V=601: K1 17.6 -> 2.0 ms)
-    if (mis && cvt && nch >= 16) w = wpr > 1 ? 2 : 3;
-    if (mis && cvt && nch >= 12 && nch < 16 && wpr > 1) w = 3;
+    // fp16 rows with boundary masks, 16+ chunks per lane in one wave: 132-140 VGPRs, a few more than 4
+    // waves allow (V=8201: K1 0.79 ms at 3 waves, 0.99 ms with 4-15 spilled registers at 4)
+    if (mis && cvt && nch >= 16 && wpr == 1) w = 3;
     return w;
 }
 [[maybe_unused]] constexpr int k3_waves(int nch, int epc) {
-    // NCH = 4: 16-bit logits want 94 VGPRs (bf16 V=1500: 1.84 -> 1.27 ms at 5 waves); fp32 runs best at 8
-    // with its 4 spilled registers (V=600: 1.71 ms against 2.60 at 5 and 2.04 at 6)
-    return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 5 : nch >= 4 ? (epc > 4 ? 5 : 8) : 8;
+    // up to 4 chunks per lane every type fits 64 VGPRs since short rows are read through a buffer
+    // descriptor (fp16 V=1000: 1.69 -> 1.46 ms at 8 waves); 6 chunks per lane measured 1-2 % better
+    // at 5 waves than at 6
+    return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 5 : 8;
 }
 template <typename DT>
 constexpr bool kCvtUnpack = sizeof(typename DT::elem) == 2 && !__is_same(typename DT::elem, __bf16);
