@@ -2,7 +2,8 @@
 
 Scope: the one hot path the reference reaches at /root/reference/src/rnnt/model.py:116 plus the
 batch-sharding harness that replaces its ``DataParallel`` use (bin/train.py:241-244).
-``JointNet`` / ``joint_hidden`` are the first widening next to that path.
+``JointNet`` / ``joint_hidden`` are the first widening next to that path,
+``greedy_decode`` the decode inner step (rank 4), ``GuardedStep`` the loss's consumer (rank 3).
 See DESIGN.md.  Importing this package does not load the HIP library; the first loss call does,
 and raises if ``rnnt_amd/lib/librnnt_mi355.so`` is missing (no fallback exists).
 """
@@ -10,7 +11,8 @@ from .loss import RNNTLoss, rnnt_loss, certify_inputs  # noqa: F401
 from .decode import greedy_decode, row_argmax  # noqa: F401
 from .joint import JointNet, joint_hidden  # noqa: F401
 from .parallel import ShardedRNNTLoss, balanced_assignment, shard_bounds, shard_batch  # noqa: F401
+from .train_step import GuardedStep  # noqa: F401
 
 __all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch",
-           "balanced_assignment", "JointNet", "joint_hidden", "greedy_decode", "row_argmax"]
+           "balanced_assignment", "JointNet", "joint_hidden", "greedy_decode", "row_argmax", "GuardedStep"]
 __version__ = "0.1.0"
