@@ -158,6 +158,16 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
  */
 rnntStatus_t rnnt_row_argmax(const void *x, int rows, int V, rnntDtype_t dtype, int *out, void *stream);
 
+/*
+ * The same with the score of the prediction: logp[r] = max_v log_softmax(x[r, :])_v, the pair
+ * `logp_targets, positions = torch.max(self.softmax(log_probs)..., dim=1)` of the reference's batched greedy
+ * search (/root/reference/src/rnnt/beam_searcher.py:91-93) for all rows in one launch.  A row holding a NaN
+ * or +inf gives NaN, as torch does.  logp may be NULL (then this is rnnt_row_argmax).
+ * rnnt_amd/decode.py builds the loop of beam_searcher.py:65-127 on it.
+ */
+rnntStatus_t rnnt_row_max_logp(const void *x, int rows, int V, rnntDtype_t dtype, int *out, float *logp,
+                               void *stream);
+
 /* hipEvent helpers so a ctypes caller (bench.py) can time stages without a HIP binding. */
 rnntStatus_t rnnt_event_create(void **event);
 rnntStatus_t rnnt_event_destroy(void *event);

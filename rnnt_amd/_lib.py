@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
     "rnnt_row_argmax",
+    "rnnt_row_max_logp",
     "rnnt_event_create",
     "rnnt_event_destroy",
     "rnnt_event_record",
@@ -120,6 +121,8 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_hidden_backward.restype = ctypes.c_int
         lib.rnnt_row_argmax.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_row_argmax.restype = ctypes.c_int
+        lib.rnnt_row_max_logp.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_void_p]
+        lib.rnnt_row_max_logp.restype = ctypes.c_int
         lib.rnnt_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         lib.rnnt_event_create.restype = ctypes.c_int
         lib.rnnt_event_destroy.argtypes = [ctypes.c_void_p]

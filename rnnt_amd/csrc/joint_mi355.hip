@@ -272,9 +272,12 @@ __device__ __forceinline__ bool better(const Best &a, const Best &b) {  // a bea
     if (a.v != b.v) return a.v > b.v;
     return a.i < b.i;
 }
+// With `logp` the kernel also gives max(log_softmax(row)) = (x_max - max) - log(sum exp(x - max)), the score the
+// reference's batched greedy search adds per emitted symbol (src/rnnt/beam_searcher.py:91-93,101); the row is
+// read a second time (it is L2-resident: at most a few tens of KB).  NaN / +inf rows give NaN as in torch.
 template <typename DT>
 __global__ __launch_bounds__(256) void row_argmax_kernel(const typename DT::elem *__restrict__ x, int rows, int V,
-                                                         int *__restrict__ out) {
+                                                         int *__restrict__ out, float *__restrict__ logp) {
     const int lane = threadIdx.x & (kWave - 1);
     const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     if (r >= rows) return;
@@ -294,6 +297,12 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const typename DT::elem
         if (better(o, best)) best = o;
     }
     if (lane == 0) out[r] = best.i;
+    if (logp == nullptr) return;
+    const float m = best.nan ? __builtin_nanf("") : best.v;
+    float sum = 0.0f;
+    for (int v = lane; v < V; v += kWave) sum += __expf(DT::to_float(row[v]) - m);
+    sum = wave_sum(sum);
+    if (lane == 0) logp[r] = (m - m) - __logf(sum);  // m - m: NaN for an infinite maximum, as x - max is in torch
 }
 
 inline int frame_chunks(int T) { return (T + kTC - 1) / kTC; }
@@ -403,20 +412,24 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
 }
 
 rnntStatus_t rnnt_row_argmax(const void *x, int rows, int V, rnntDtype_t dtype, int *out, void *stream) {
+    return rnnt_row_max_logp(x, rows, V, dtype, out, nullptr, stream);
+}
+
+rnntStatus_t rnnt_row_max_logp(const void *x, int rows, int V, rnntDtype_t dtype, int *out, float *logp, void *stream) {
     if (x == nullptr || out == nullptr || rows < 1 || V < 1) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((rows + 3) / 4), block(256);
     switch (dtype) {
         case RNNT_DTYPE_F32:
-            hipLaunchKernelGGL((row_argmax_kernel<F32>), grid, block, 0, st, static_cast<const float *>(x), rows, V, out);
+            hipLaunchKernelGGL((row_argmax_kernel<F32>), grid, block, 0, st, static_cast<const float *>(x), rows, V, out, logp);
             break;
         case RNNT_DTYPE_BF16:
             hipLaunchKernelGGL((row_argmax_kernel<BF16>), grid, block, 0, st, static_cast<const __bf16 *>(x), rows, V,
-                               out);
+                               out, logp);
             break;
         case RNNT_DTYPE_F16:
             hipLaunchKernelGGL((row_argmax_kernel<F16>), grid, block, 0, st, static_cast<const _Float16 *>(x), rows, V,
-                               out);
+                               out, logp);
             break;
         default: return RNNT_STATUS_INVALID_VALUE;
     }

@@ -11,7 +11,7 @@ frame), with one host round trip per window or emission instead of one per frame
 """
 from __future__ import annotations
 
-from typing import Callable, List
+from typing import Callable, List, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -36,6 +36,114 @@ def row_argmax(x: torch.Tensor) -> torch.Tensor:
         _lib.check(_lib.load().rnnt_row_argmax(x.data_ptr(), x.shape[0], x.shape[1], _DTYPES[x.dtype], out.data_ptr(),
                                                torch.cuda.current_stream(x.device).cuda_stream), "rnnt_row_argmax")
     return out
+
+
+def row_max_logp(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(int32[R], float32[R])``: argmax of every row of ``x[R, V]`` as :func:`row_argmax` gives it, and
+    ``max(log_softmax(row))``, i.e. ``torch.max(F.log_softmax(x, -1), dim=1)`` in one launch."""
+    if x.dim() != 2 or x.shape[0] < 1 or x.shape[1] < 1:
+        raise ValueError("x must be a non-empty [rows, V] tensor")
+    if x.dtype not in _DTYPES:
+        raise TypeError("x must be torch.float32, torch.bfloat16 or torch.float16")
+    if not x.is_cuda:
+        raise RuntimeError("rnnt_amd.row_max_logp computes on MI355X (ROCm device tensors) only")
+    x = x.contiguous()
+    with torch.cuda.device(x.device):
+        out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+        logp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().rnnt_row_max_logp(x.data_ptr(), x.shape[0], x.shape[1], _DTYPES[x.dtype],
+                                                 out.data_ptr(), logp.data_ptr(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream), "rnnt_row_max_logp")
+    return out, logp
+
+
+def _joint_weights(joint: JointNet, he: int):
+    first, out = joint.mlp[0], joint.mlp[2]
+    if joint.joint == "concat":
+        return first, out, first.weight[:, :he], first.weight[:, he:]
+    return first, out, first.weight, first.weight
+
+
+@torch.no_grad()
+def greedy_search_batch(encoder_output: torch.Tensor, decoder: Callable, joint: JointNet, blank: int = 0,
+                        window: int = 32):
+    """The reference's batched greedy search, ``TransducerBeamSearcher.transducer_greedy_decode``
+    (/root/reference/src/rnnt/beam_searcher.py:65-127), with one host round trip per window of frames.
+
+    The reference walks the frames of the whole batch together and reads ``positions[i].item()`` for every
+    utterance at every frame.  An utterance's decoder state only changes when it emits, so here every
+    utterance keeps its own frame pointer: each iteration evaluates the joint for the next ``window`` frames
+    of all unfinished utterances against their current decoder outputs (one ``tanh`` kernel, one library
+    GEMM, one ``rnnt_row_max_logp`` launch), copies the ``[A, window]`` predictions and scores to the host
+    once, advances each utterance to just after its first non-blank frame, and steps the decoder for those
+    that emitted (one batched call, hidden states gathered and scattered as ``:107-120`` does).
+
+    Args:
+        encoder_output: ``[B, T, He]``; as in the reference all ``T`` frames of every utterance are decoded.
+        decoder: called as the reference calls it: ``decoder(tokens[n,1])`` and
+            ``decoder(tokens[n,1], hidden=hidden)`` -> ``(out[n,1,Hd], hidden)``, hidden a tensor or an
+            ``(h, c)`` tuple shaped ``[layers, n, Hd]``.
+    Returns:
+        ``(predictions, mean(exp(score)), None, None)`` as the reference's 4-tuple (``:122-127``): token lists
+        per utterance, and the batch mean of ``exp`` of each utterance's summed log-probabilities of its
+        emitted symbols.
+    """
+    if encoder_output.dim() != 3:
+        raise ValueError("encoder_output must be [B, T, He]")
+    if window < 1:
+        raise ValueError("window must be positive")
+    B, T, he = encoder_output.shape
+    dev = encoder_output.device
+    first, out, w_enc, w_dec = _joint_weights(joint, he)
+    enc_proj = F.linear(encoder_output, w_enc, first.bias)                      # [B, T, H], once
+
+    predictions: List[List[int]] = [[] for _ in range(B)]
+    scores = [0.0] * B
+    input_decoder = torch.full((B, 1), blank, dtype=torch.long, device=dev)     # BOS = blank (:73-80)
+    out_pn, hidden = decoder(input_decoder)                                     # [B, 1, Hd]
+    dec_proj = F.linear(out_pn, w_dec)                                          # [B, 1, H]
+    ptr = [0] * B
+    offs = torch.arange(window, device=dev)
+    while True:
+        active = [b for b in range(B) if ptr[b] < T]
+        if not active:
+            break
+        act = torch.tensor(active, device=dev)
+        start = torch.tensor([ptr[b] for b in active], device=dev)
+        frames = torch.clamp(start[:, None] + offs[None, :], max=T - 1)         # [A, W]; surplus frames ignored below
+        win = enc_proj[act[:, None], frames]                                    # [A, W, H]
+        h = joint_hidden(win.contiguous(), dec_proj[act].contiguous())          # [A, W, 1, H]
+        pos, logp = row_max_logp(out(h.reshape(len(active) * window, -1)))
+        host = torch.stack((pos.to(torch.float32), logp)).cpu()                 # the one host round trip (V < 2^24)
+        pos_h = host[0].reshape(len(active), window).to(torch.int64).tolist()
+        logp_h = host[1].reshape(len(active), window).tolist()
+        emitted = []
+        for a, b in enumerate(active):
+            n = min(window, T - ptr[b])
+            step = next((j for j in range(n) if pos_h[a][j] != blank), None)
+            if step is None:
+                ptr[b] += n
+                continue
+            predictions[b].append(pos_h[a][step])
+            scores[b] += logp_h[a][step]
+            ptr[b] += step + 1                                                  # one symbol per frame at most
+            emitted.append(b)
+        if emitted:
+            sel = torch.tensor(emitted, device=dev)
+            input_decoder[sel, 0] = torch.tensor([predictions[b][-1] for b in emitted], device=dev)
+            if isinstance(hidden, tuple):
+                sel_hidden = tuple(hx[:, sel, :].contiguous() for hx in hidden)
+            else:
+                sel_hidden = hidden[:, sel, :].contiguous()
+            sel_out, sel_hidden = decoder(input_decoder[sel], hidden=sel_hidden)
+            out_pn[sel] = sel_out
+            if isinstance(hidden, tuple):
+                for hx, new in zip(hidden, sel_hidden):
+                    hx[:, sel, :] = new
+            else:
+                hidden[:, sel, :] = sel_hidden
+            dec_proj[sel] = F.linear(sel_out, w_dec)
+    return predictions, torch.tensor(scores).exp().mean(), None, None
 
 
 @torch.no_grad()

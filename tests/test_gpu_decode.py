@@ -88,3 +88,91 @@ def test_greedy_decode_all_blank_and_argument_checks():
         rnnt_amd.greedy_decode(enc.unsqueeze(0), 20, decoder, joint)
     with pytest.raises(RuntimeError):
         rnnt_amd.row_argmax(torch.zeros(2, 3))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,V", [(1, 1), (3, 7), (32, 4232), (64, 5455), (2, 70001)])
+def test_row_max_logp_matches_torch(dtype, R, V):
+    import rnnt_amd
+
+    g = torch.Generator(device=DEV).manual_seed(R * 17 + V)
+    x = (torch.randn(R, V, device=DEV, generator=g) * 3.0).to(dtype)
+    pos, logp = rnnt_amd.row_max_logp(x)
+    ref_logp, ref_pos = torch.max(torch.log_softmax(x.float(), dim=-1), dim=1)
+    assert torch.equal(pos.long(), ref_pos)
+    assert torch.equal(pos, rnnt_amd.row_argmax(x))
+    torch.testing.assert_close(logp, ref_logp, rtol=1e-5, atol=2e-6)
+
+
+def test_row_max_logp_special_rows():
+    import rnnt_amd
+
+    x = torch.zeros(5, 200, device=DEV)
+    x[0, 3] = 1e4                      # large offset: logp ~ 0
+    x[1, :] = -float("inf")            # all -inf: NaN as torch (-inf - -inf)
+    x[2, 50] = float("nan")
+    x[3, 7] = float("inf")
+    x[4, :] = -1e4                     # uniform: -log(200)
+    pos, logp = rnnt_amd.row_max_logp(x)
+    ref_logp, ref_pos = torch.max(torch.log_softmax(x, dim=-1), dim=1)
+    assert pos.tolist() == [3, 0, 50, 7, 0]
+    assert torch.isnan(logp[[1, 2, 3]]).all() and torch.isnan(ref_logp[[1, 2, 3]]).all()
+    torch.testing.assert_close(logp[[0, 4]], ref_logp[[0, 4]], rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        rnnt_amd.row_max_logp(torch.zeros(2, 3))
+
+
+@pytest.mark.parametrize("seed,window,lstm", [(0, 32, True), (1, 1, True), (2, 7, False), (3, 64, True), (4, 5, False)])
+def test_greedy_search_batch_equals_reference_loop(seed, window, lstm):
+    """beam_searcher.py:65-127 restated (oracle/decode_oracle.py) against rnnt_amd.greedy_search_batch on
+    the same modules: same tokens for every utterance and the same batch score."""
+    import rnnt_amd
+    from oracle.decode_oracle import greedy_search_batch_reference
+
+    torch.manual_seed(100 + seed)
+    B, T, He, Hd, H, V = 5, 60, 24, 16, 48, 41
+    joint = rnnt_amd.JointNet(He + Hd, H, V).to(DEV)
+    with torch.no_grad():
+        joint.mlp[2].bias[0] += 1.5
+        joint.mlp[2].weight *= 3.0
+    decoder = Decoder(20, V, Hd).to(DEV) if lstm else GruDecoder(20, V, Hd).to(DEV)
+    enc = torch.randn(B, T, He, device=DEV) * 2.0
+
+    (ref_pred, ref_score, n1, n2), margin = greedy_search_batch_reference(enc, decoder, lambda e, d: joint(e, d))
+    pred, score, m1, m2 = rnnt_amd.greedy_search_batch(enc, decoder, joint, window=window)
+    assert n1 is None and n2 is None and m1 is None and m2 is None
+    assert any(0 < len(p) < T for p in ref_pred)
+    if margin <= 1e-5:
+        pytest.skip(f"reference top-2 margin {margin:.2e} is at rounding level")
+    assert pred == ref_pred
+    assert float(score) == pytest.approx(float(ref_score), rel=1e-4, abs=1e-12)
+
+
+class GruDecoder(nn.Module):
+    """A prediction network whose hidden state is a single tensor (the other branch of
+    beam_searcher.py:5-23)."""
+
+    def __init__(self, hidden, vocab, out):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab, hidden, padding_idx=0)
+        self.rnn = nn.GRU(hidden, hidden, 1, batch_first=True)
+        self.output_proj = nn.Linear(hidden, out)
+
+    def forward(self, inputs, length=None, hidden=None):
+        o, hidden = self.rnn(self.embedding(inputs), hidden)
+        return self.output_proj(o), hidden
+
+
+def test_greedy_search_batch_all_blank_and_checks():
+    import rnnt_amd
+
+    torch.manual_seed(3)
+    joint = rnnt_amd.JointNet(8 + 8, 16, 11).to(DEV)
+    with torch.no_grad():
+        joint.mlp[2].bias[0] += 100.0
+    decoder = Decoder(8, 11, 8).to(DEV)
+    enc = torch.randn(3, 20, 8, device=DEV)
+    pred, score, _, _ = rnnt_amd.greedy_search_batch(enc, decoder, joint, window=6)
+    assert pred == [[], [], []] and float(score) == 1.0   # exp(0) for every utterance, as the reference
+    with pytest.raises(ValueError):
+        rnnt_amd.greedy_search_batch(enc[0], decoder, joint)

@@ -2,7 +2,8 @@
 """Greedy decoding of one utterance at the reference's sizes (T=400 frames, He=Hd=320, H=512, V=4232,
 1-layer LSTM decoder of 512 units as config/aishell.yaml): rnnt_amd.greedy_decode (windowed joint)
 against the reference's frame-by-frame loop (model.py:145-165, restated below)
-with the same modules on the same MI355X.  Prints one JSON line."""
+with the same modules on the same MI355X, and the batched search rnnt_amd.greedy_search_batch against the
+reference's batched loop (beam_searcher.py:65-127, restated below).  Prints one JSON line."""
 import json
 import os
 import sys
@@ -30,6 +31,33 @@ def greedy_decode_reference(enc_state, length, decoder, joint_fn):
             dec_state, hidden = decoder(torch.full((1, 1), pred, dtype=torch.long, device=enc_state.device),
                                         hidden=hidden)
     return token_list
+
+
+@torch.no_grad()
+def greedy_search_batch_reference(encoder_output, decoder, joint_fn, blank_id=0):
+    """The reference's batched formulation (beam_searcher.py:65-127): one joint + log_softmax + max per frame
+    for the batch, `.item()` per utterance per frame, one decoder call per frame for those that emitted."""
+    B = encoder_output.size(0)
+    pred = [[] for _ in range(B)]
+    scores = [0.0] * B
+    input_decoder = torch.ones((B, 1), device=encoder_output.device, dtype=torch.int64) * blank_id
+    out_PN, hidden = decoder(input_decoder)
+    for t in range(encoder_output.size(1)):
+        logp, pos = torch.max(F.log_softmax(joint_fn(encoder_output[:, t, :], out_PN[:, 0, :]), dim=-1), dim=1)
+        upd = []
+        for i in range(B):
+            if pos[i].item() != blank_id:
+                pred[i].append(pos[i].item())
+                scores[i] += logp[i]
+                input_decoder[i][0] = pos[i]
+                upd.append(i)
+        if upd:
+            sel_h = (hidden[0][:, upd, :].contiguous(), hidden[1][:, upd, :].contiguous())
+            sel_out, sel_h = decoder(input_decoder[upd, :], hidden=sel_h)
+            out_PN[upd] = sel_out
+            hidden[0][:, upd, :] = sel_h[0]
+            hidden[1][:, upd, :] = sel_h[1]
+    return pred, torch.Tensor(scores).exp().mean()
 
 
 class Decoder(nn.Module):
@@ -73,6 +101,15 @@ def main():
         t, got = timed(lambda: rnnt_amd.greedy_decode(enc, T, decoder, joint, window=w))
         res[f"window{w}_ms"] = round(t, 3)
         res[f"window{w}_same_tokens"] = got == ref
+    B = 16
+    encb = torch.randn(B, T, He, device=dev)
+    t_ref, (refb, _) = timed(lambda: greedy_search_batch_reference(encb, decoder, lambda e, d: joint(e, d)), reps=3)
+    res["batch"] = {"workload": f"batched greedy search (beam_searcher.py:65-127), B={B}, same sizes",
+                    "tokens": sum(len(p) for p in refb), "reference_loop_ms": round(t_ref, 3)}
+    for w in (16, 32):
+        t, got = timed(lambda: rnnt_amd.greedy_search_batch(encb, decoder, joint, window=w), reps=3)
+        res["batch"][f"window{w}_ms"] = round(t, 3)
+        res["batch"][f"window{w}_same_tokens"] = got[0] == refb
     print(json.dumps(res))
 
 
