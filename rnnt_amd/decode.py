@@ -114,9 +114,9 @@ def greedy_search_batch(encoder_output: torch.Tensor, decoder: Callable, joint: 
         win = enc_proj[act[:, None], frames]                                    # [A, W, H]
         h = joint_hidden(win.contiguous(), dec_proj[act].contiguous())          # [A, W, 1, H]
         pos, logp = row_max_logp(out(h.reshape(len(active) * window, -1)))
-        host = torch.stack((pos.to(torch.float32), logp)).cpu()                 # the one host round trip (V < 2^24)
-        pos_h = host[0].reshape(len(active), window).to(torch.int64).tolist()
-        logp_h = host[1].reshape(len(active), window).tolist()
+        host = torch.stack((pos, logp.view(torch.int32))).cpu()                 # the one host round trip
+        pos_h = host[0].reshape(len(active), window).tolist()
+        logp_h = host[1].view(torch.float32).reshape(len(active), window).tolist()
         emitted = []
         for a, b in enumerate(active):
             n = min(window, T - ptr[b])
