@@ -154,6 +154,7 @@ struct Lattice {      // device pointers into the workspace
     // fp16 rows with boundary masks, 16+ chunks per lane in one wave: 132-140 VGPRs, a few more than 4
     // waves allow (V=8201: K1 0.79 ms at 3 waves, 0.99 ms with 4-15 spilled registers at 4)
     if (mis && cvt && nch >= 16 && wpr == 1) w = 3;
+    if (mis && cvt && nch == 10 && wpr == 1) w = 5;  // 13 spilled registers at 6
     return w;
 }
 [[maybe_unused]] constexpr int k3_waves(int nch, int epc) {
@@ -1159,8 +1160,12 @@ struct Tile {
     int nseg;  // segments (waves) per node
     bool mis;  // rows are not 16-byte aligned: the MIS kernels (boundary chunks masked / stored by element)
 };
-constexpr int kNchSizes[] = {1, 2, 4, 6, 8, 12, 16, 17};
-inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_seg) {
+// K1 also has 10 and 14: the read-only pass gains from a closer fit (bf16 V=4232: 0.81 -> 0.71 ms with 10
+// instead of 12 chunks per lane, fp32 V=9000: 1.47 -> 1.30 ms); K3 measured the same or 1-4 % worse with
+// them (fp32 V=2400: 3.48 -> 3.61 ms) and keeps the coarser list.
+constexpr int kNchSizes[] = {1, 2, 4, 6, 8, 10, 12, 14, 16, 17};
+constexpr bool nch_for_k3(int sz) { return sz != 10 && sz != 14; }
+inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_seg, bool k3 = false) {
     Tile t = {0, 0, false};
     const int epc = 16 / elem_size(dtype);
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(p0) % 16, a1 = p1 ? reinterpret_cast<uintptr_t>(p1) % 16 : a0;
@@ -1179,7 +1184,7 @@ inline Tile pick_tile(const void *p0, const void *p1, int V, int dtype, int max_
     }
     const int per = (need + nseg - 1) / nseg;
     for (int sz : kNchSizes)
-        if (per <= sz) {
+        if (per <= sz && (!k3 || nch_for_k3(sz))) {
             t.nch = sz;
             t.nseg = nseg;
             return t;
@@ -1210,7 +1215,8 @@ inline int tuning_knob(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-#define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)
+#define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(10) M(12) M(14) M(16) M(17)
+#define FOR_EACH_NCH_K3(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)
 
 // Small rows: shape index into {LPR, NCH, NR} = {4,1,8} {4,2,4} {8,2,4} {8,4,2} {8,8,1} {8,16,1}, or -1
 // when a row can span more than 128 chunks (the one-wave-per-node kernels take those).  Few lanes per
@@ -1328,7 +1334,7 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
         }
         return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
     }
-    const Tile t = pick_tile(acts, grads, V, o.dtype, 1 << 20);
+    const Tile t = pick_tile(acts, grads, V, o.dtype, 1 << 20, true);
     int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K3_GRID", 0);
     if (g > 0) grid = g;
@@ -1341,7 +1347,7 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
         else                                                                                          \
             hipLaunchKernelGGL((rnnt_k3_grad<DT, N, false>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg); \
         break;
-        FOR_EACH_NCH(CASE)
+        FOR_EACH_NCH_K3(CASE)
 #undef CASE
         default:
             hipLaunchKernelGGL((rnnt_k3_grad_generic<DT>), dim3(grid), dim3(block), 0, st, K3_ARGS);
