@@ -1275,14 +1275,15 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     if (g > 0) grid = g;
 #define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
 #define K1_LAUNCH(N, W, M) hipLaunchKernelGGL((rnnt_k1_lse<DT, N, W, M>), dim3(grid), dim3(block), 0, st, K1_ARGS)
+// several waves per node only occur with 9+ chunks per lane (pick_tile): the others are not instantiated
 #define CASE(N)                                                                                        \
     case N:                                                                                            \
-        if (t.nseg == 1) {                                                                             \
+        if (N < 9 || t.nseg == 1) {                                                                    \
             if (t.mis) K1_LAUNCH(N, 1, true); else K1_LAUNCH(N, 1, false);                             \
         } else if (t.nseg == 2) {                                                                      \
-            if (t.mis) K1_LAUNCH(N, 2, true); else K1_LAUNCH(N, 2, false);                             \
+            if (t.mis) K1_LAUNCH(N, (N < 9 ? 1 : 2), true); else K1_LAUNCH(N, (N < 9 ? 1 : 2), false); \
         } else {                                                                                       \
-            if (t.mis) K1_LAUNCH(N, 4, true); else K1_LAUNCH(N, 4, false);                             \
+            if (t.mis) K1_LAUNCH(N, (N < 9 ? 1 : 4), true); else K1_LAUNCH(N, (N < 9 ? 1 : 4), false); \
         }                                                                                              \
         break;
     const bool vectorisable = V % DT::EPC == 0 && reinterpret_cast<uintptr_t>(acts) % 16 == 0;

@@ -26,10 +26,7 @@ def test_no_reachable_kernel_spills(src, tmp_path):
     spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", out.stderr)]
     assert names and len(names) == len(spills)
     bad = []
-    for name, spilled in zip(names, spills):
-        m = re.search(r"rnnt_k1_lseIN17rnnt_mi355_detail\d\w+?ELi(\d+)ELi(\d)E", name)
-        if m and int(m.group(2)) > 1 and int(m.group(1)) < 10:
-            continue  # K1 with several waves per node is only launched with 9+ chunks per lane (pick_tile)
+    for name, spilled in zip(names, spills):  # (only reachable instantiations exist)
         if spilled > MAX_SPILLED_VGPRS:
             bad.append((name, spilled))
     assert not bad, bad
