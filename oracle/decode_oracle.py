@@ -47,37 +47,41 @@ def greedy_search_batch_reference(encoder_output, decoder, joint_fn, blank_id=0)
     ``self.softmax``, which is never set); the restatement takes what :92 applies anyway, a
     LogSoftmax over the vocabulary.  PARITY UNPINNED: no fixtures exist for this path.
     """
-    B = encoder_output.size(0)
-    hyp = {"prediction": [[] for _ in range(B)], "logp_scores": [0.0 for _ in range(B)]}
+    n_utt, n_frames = encoder_output.size(0), encoder_output.size(1)
+    tokens = [[] for _ in range(n_utt)]
+    logp_sum = [0.0] * n_utt
     margin = float("inf")
-    input_decoder = torch.ones((B, 1), device=encoder_output.device, dtype=torch.int64) * blank_id
-    out_PN, hidden = decoder(input_decoder)
-    for t_step in range(encoder_output.size(1)):
-        logits = joint_fn(encoder_output[:, t_step, :], out_PN[:, 0, :])
-        log_probs = F.log_softmax(logits, dim=-1)
-        logp_targets, positions = torch.max(log_probs, dim=1)
-        top2 = torch.topk(log_probs, 2, dim=1).values
-        margin = min(margin, float((top2[:, 0] - top2[:, 1]).min()))
-        have_update_hyp = []
-        for i in range(positions.size(0)):
-            if positions[i].item() != blank_id:
-                hyp["prediction"][i].append(positions[i].item())
-                hyp["logp_scores"][i] += float(logp_targets[i])
-                input_decoder[i][0] = positions[i]
-                have_update_hyp.append(i)
-        if len(have_update_hyp) > 0:
-            selected_input = input_decoder[have_update_hyp, :]
-            if isinstance(hidden, tuple):
-                selected_hidden = (hidden[0][:, have_update_hyp, :].contiguous(),
-                                   hidden[1][:, have_update_hyp, :].contiguous())
-            else:
-                selected_hidden = hidden[:, have_update_hyp, :].contiguous()
-            selected_out, selected_hidden = decoder(selected_input, hidden=selected_hidden)
-            out_PN[have_update_hyp] = selected_out
-            if isinstance(hidden, tuple):
-                hidden[0][:, have_update_hyp, :] = selected_hidden[0]
-                hidden[1][:, have_update_hyp, :] = selected_hidden[1]
-            else:
-                hidden[:, have_update_hyp, :] = selected_hidden
-    score = torch.Tensor(hyp["logp_scores"]).exp().mean()
-    return (hyp["prediction"], score, None, None), margin
+
+    def take(state, rows):      # hidden state of the chosen utterances (LSTM pair or single tensor)
+        if isinstance(state, tuple):
+            return tuple(part[:, rows, :].contiguous() for part in state)
+        return state[:, rows, :].contiguous()
+
+    def put(state, rows, new):  # ... and written back in place
+        if isinstance(state, tuple):
+            for part, fresh in zip(state, new):
+                part[:, rows, :] = fresh
+        else:
+            state[:, rows, :] = new
+
+    last_token = torch.full((n_utt, 1), blank_id, device=encoder_output.device, dtype=torch.int64)  # :73-80
+    pred_out, state = decoder(last_token)                                                          # :82
+    for t in range(n_frames):                                                                      # :84
+        log_probs = F.log_softmax(joint_fn(encoder_output[:, t, :], pred_out[:, 0, :]), dim=-1)    # :86-92
+        best_logp, best = torch.max(log_probs, dim=1)                                              # :91-93
+        two = torch.topk(log_probs, 2, dim=1).values
+        margin = min(margin, float((two[:, 0] - two[:, 1]).min()))
+        stepped = []
+        for b in range(n_utt):                                                                     # :96-103
+            sym = best[b].item()
+            if sym != blank_id:
+                tokens[b].append(sym)
+                logp_sum[b] += float(best_logp[b])
+                last_token[b, 0] = sym
+                stepped.append(b)
+        if stepped:                                                                                # :104-120
+            new_out, new_state = decoder(last_token[stepped, :], hidden=take(state, stepped))
+            pred_out[stepped] = new_out
+            put(state, stepped, new_state)
+    score = torch.Tensor(logp_sum).exp().mean()                                                    # :124
+    return (tokens, score, None, None), margin

@@ -37,27 +37,28 @@ def greedy_decode_reference(enc_state, length, decoder, joint_fn):
 def greedy_search_batch_reference(encoder_output, decoder, joint_fn, blank_id=0):
     """The reference's batched formulation (beam_searcher.py:65-127): one joint + log_softmax + max per frame
     for the batch, `.item()` per utterance per frame, one decoder call per frame for those that emitted."""
-    B = encoder_output.size(0)
-    pred = [[] for _ in range(B)]
-    scores = [0.0] * B
-    input_decoder = torch.ones((B, 1), device=encoder_output.device, dtype=torch.int64) * blank_id
-    out_PN, hidden = decoder(input_decoder)
+    n_utt = encoder_output.size(0)
+    tokens = [[] for _ in range(n_utt)]
+    logp_sum = [0.0] * n_utt
+    last_token = torch.full((n_utt, 1), blank_id, device=encoder_output.device, dtype=torch.int64)
+    pred_out, (h, c) = decoder(last_token)
     for t in range(encoder_output.size(1)):
-        logp, pos = torch.max(F.log_softmax(joint_fn(encoder_output[:, t, :], out_PN[:, 0, :]), dim=-1), dim=1)
-        upd = []
-        for i in range(B):
-            if pos[i].item() != blank_id:
-                pred[i].append(pos[i].item())
-                scores[i] += logp[i]
-                input_decoder[i][0] = pos[i]
-                upd.append(i)
-        if upd:
-            sel_h = (hidden[0][:, upd, :].contiguous(), hidden[1][:, upd, :].contiguous())
-            sel_out, sel_h = decoder(input_decoder[upd, :], hidden=sel_h)
-            out_PN[upd] = sel_out
-            hidden[0][:, upd, :] = sel_h[0]
-            hidden[1][:, upd, :] = sel_h[1]
-    return pred, torch.Tensor(scores).exp().mean()
+        best_logp, best = torch.max(F.log_softmax(joint_fn(encoder_output[:, t, :], pred_out[:, 0, :]), dim=-1), dim=1)
+        stepped = []
+        for b in range(n_utt):                      # one host read per utterance per frame, as the reference
+            sym = best[b].item()
+            if sym != blank_id:
+                tokens[b].append(sym)
+                logp_sum[b] += best_logp[b]
+                last_token[b, 0] = sym
+                stepped.append(b)
+        if stepped:
+            new_out, (nh, nc) = decoder(last_token[stepped, :],
+                                        hidden=(h[:, stepped, :].contiguous(), c[:, stepped, :].contiguous()))
+            pred_out[stepped] = new_out
+            h[:, stepped, :] = nh
+            c[:, stepped, :] = nc
+    return tokens, torch.Tensor(logp_sum).exp().mean()
 
 
 class Decoder(nn.Module):
