@@ -9,7 +9,7 @@ from torch import nn
 
 import rnnt_amd
 from rnnt_amd.train_step import GuardedStep
-from test_train_step import reference_iter_one_batch
+from oracle.train_step_oracle import consume_loss_reference
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -70,7 +70,7 @@ def test_micro_steps_without_host_sync_match_reference_loop():
     total_ref = 0.0
     for step, ((x, labels, al, ll), tok) in enumerate(zip(data, bos)):
         loss = crit(ref_model(x, tok), labels, al, ll)
-        lv, gn = reference_iter_one_batch(loss, ref_model, 1, accum, max_norm)
+        lv, gn = consume_loss_reference(loss, ref_model.parameters(), 1, accum, max_norm)
         total_ref += lv
         assert float(returned[step][0]) == pytest.approx(float(lv), rel=1e-5, abs=1e-7)
         assert float(returned[step][1]) == pytest.approx(float(gn), rel=1e-5, abs=1e-7)

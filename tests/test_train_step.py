@@ -1,29 +1,14 @@
-"""GuardedStep against the reference's own consumer loop, restated with its host-side branches
-(bin/train.py:34-51: isnan / isinf -> return 0, 0; loss / accumulation_steps; backward;
-clip_grad_norm_; loss.item()).  Same model, same micro-batches, one of them NaN and one infinite."""
+"""GuardedStep against the reference's consumer of the loss restated with its host-side decisions
+(oracle/train_step_oracle.py, bin/train.py:34-51).  Same model, same micro-batches, two of them NaN
+and one infinite."""
 import copy
 
 import pytest
 import torch
 from torch import nn
 
+from oracle.train_step_oracle import consume_loss_reference
 from rnnt_amd.train_step import GuardedStep
-
-
-def reference_iter_one_batch(loss, model, num_gpu, accumulation_steps, max_grad_norm):
-    if num_gpu > 1:
-        loss = loss / num_gpu
-    if torch.isnan(loss):
-        return 0, 0
-    if torch.isinf(loss):
-        return 0, 0
-    loss = loss / accumulation_steps
-    loss.backward()
-    if max_grad_norm:
-        grad_norm = nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
-    else:
-        grad_norm = 0
-    return loss.item(), grad_norm
 
 
 def tiny_model(seed):
@@ -59,7 +44,7 @@ def test_matches_reference_consumer(accum, max_norm, num_gpu):
     opt_ref.zero_grad()
     opt.zero_grad()
     for step, (x, poison) in enumerate(batches(9, 11, {2: "nan", 5: "inf", 6: "nan"})):
-        lv_ref, gn_ref = reference_iter_one_batch(loss_of(ref_model, x, poison), ref_model, num_gpu, accum, max_norm)
+        lv_ref, gn_ref = consume_loss_reference(loss_of(ref_model, x, poison), ref_model.parameters(), num_gpu, accum, max_norm)
         total_ref += lv_ref
         lv, gn = guard(loss_of(model, x, poison))
         assert lv.shape == () and gn.shape == ()
