@@ -14,6 +14,10 @@ Three independent statements of the loss the reference obtains from
 * :func:`rnnt_loss_bruteforce` — explicit enumeration of every alignment of a
   tiny lattice.
 
+Restatements of the rows next to the loss live beside it, under the same rule:
+``joint_oracle`` (src/rnnt/model.py:39-59), ``decode_oracle`` (model.py:145-165 and
+beam_searcher.py:65-127) and ``train_step_oracle`` (bin/train.py:34-51).
+
 PARITY UNPINNED: the reference has no tests or golden vectors for this path and
 the upstream package cannot be built or imported here.  The
 three statements are checked against each other and against two known-answer
