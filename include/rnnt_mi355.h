@@ -15,7 +15,8 @@
  *   - plain C: pointers and sizes only, no C++/torch types, no exceptions.
  *   - every pointer is a DEVICE pointer (hipMalloc'ed or torch-allocated);
  *     the caller owns every buffer, including the workspace.  The library
- *     allocates nothing, keeps no global state, never synchronises the host:
+ *     allocates nothing, never synchronises the host, and keeps no state between
+ *     calls (one exception, stated there: compute_rnnt_loss_static's device array):
  *     all work is enqueued on `options.stream`.
  *   - acts   [B, maxT, maxU, V] contiguous raw (un-normalised) joint logits,
  *            maxU = max label length + 1   (model.py:115 produces this layout)
@@ -38,7 +39,8 @@ typedef enum {
     RNNT_STATUS_MEMOPS_FAILED = 1,
     RNNT_STATUS_INVALID_VALUE = 2,
     RNNT_STATUS_EXECUTION_FAILED = 3,
-    RNNT_STATUS_UNKNOWN_ERROR = 4
+    RNNT_STATUS_UNKNOWN_ERROR = 4,
+    RNNT_STATUS_STATIC_WORKSPACE_EXCEEDED = 5 /* compute_rnnt_loss_static only */
 } rnntStatus_t;
 
 /* element type of acts and grads; the lattice (lse, alpha, beta, costs) is always fp32 */
@@ -112,6 +114,23 @@ rnntStatus_t rnnt_backward(const void *acts, void *grads, const int *labels, con
 rnntStatus_t compute_rnnt_loss(const void *acts, void *grads, const int *labels,
                                const int *label_lens, const int *act_lens, int alphabet_size,
                                int minibatch, float *costs, void *workspace, rnntOptions options);
+
+/*
+ * compute_rnnt_loss without a workspace argument and without any allocation.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot allocate device memory — code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The lattice workspace is a device array of
+ * RNNT_STATIC_WORKSPACE_BYTES inside the library, one copy per GPU, held until the process ends;
+ * its address is looked up once per device on the first call there (the device must be current, as for
+ * every entry point).  A minibatch whose rnnt_get_workspace_size exceeds the array returns
+ * RNNT_STATUS_STATIC_WORKSPACE_EXCEEDED and launches nothing.  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; serialise them.  Nothing needs
+ * clearing between calls (every value read is written earlier in the same call).  Same kernels, same
+ * results bit for bit as compute_rnnt_loss.
+ */
+#define RNNT_STATIC_WORKSPACE_BYTES (32u << 20) /* 32 MiB: config 2 (B32 T400 U40) needs 21.7 MB */
+rnntStatus_t compute_rnnt_loss_static(const void *acts, void *grads, const int *labels,
+                                      const int *label_lens, const int *act_lens, int alphabet_size,
+                                      int minibatch, float *costs, rnntOptions options);
 
 /*
  * The cost reduction on its own: loss_out = sum(costs)/B (MEAN), sum (SUM) or a copy (NONE), summed in

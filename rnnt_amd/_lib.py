@@ -19,6 +19,8 @@ ABI_VERSION = 1
 
 # status codes (include/rnnt_mi355.h: rnntStatus_t)
 RNNT_STATUS_SUCCESS = 0
+RNNT_STATUS_STATIC_WORKSPACE_EXCEEDED = 5
+STATIC_WORKSPACE_BYTES = 32 << 20  # RNNT_STATIC_WORKSPACE_BYTES
 # dtype / reduction enums
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 REDUCTION_NONE, REDUCTION_MEAN, REDUCTION_SUM = 0, 1, 2
@@ -31,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "rnnt_forward",
     "rnnt_backward",
     "compute_rnnt_loss",
+    "compute_rnnt_loss_static",
     "rnnt_reduce_costs",
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
@@ -108,6 +111,8 @@ def load() -> ctypes.CDLL:
         lib.compute_rnnt_loss.argtypes = [vp, vp, ip, ip, ip, ctypes.c_int, ctypes.c_int, fp, vp,
                                           RnntOptions]
         lib.compute_rnnt_loss.restype = ctypes.c_int
+        lib.compute_rnnt_loss_static.argtypes = [vp, vp, ip, ip, ip, ctypes.c_int, ctypes.c_int, fp, RnntOptions]
+        lib.compute_rnnt_loss_static.restype = ctypes.c_int
         lib.rnnt_reduce_costs.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_reduce_costs.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -22,6 +22,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/rnnt_mi355.h"
 #include "elem_types.h"
 
@@ -1391,6 +1393,8 @@ const char *rnntGetStatusString(rnntStatus_t status) {
         case RNNT_STATUS_MEMOPS_FAILED: return "hip memcpy or memset failed";
         case RNNT_STATUS_INVALID_VALUE: return "invalid value";
         case RNNT_STATUS_EXECUTION_FAILED: return "execution failed";
+        case RNNT_STATUS_STATIC_WORKSPACE_EXCEEDED:
+            return "lattice does not fit the static workspace (RNNT_STATIC_WORKSPACE_BYTES); use compute_rnnt_loss";
         case RNNT_STATUS_UNKNOWN_ERROR:
         default: return "unknown error";
     }
@@ -1482,6 +1486,51 @@ rnntStatus_t compute_rnnt_loss(const void *acts, void *grads, const int *labels,
     if (s != RNNT_STATUS_SUCCESS || !grads) return s;
     return rnnt_backward(acts, grads, labels, act_lens, label_lens, alphabet_size, minibatch, nullptr, 0,
                          1.0f, workspace, fo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute_rnnt_loss for callers that cannot allocate (HIP graph capture, serving loops): the
+// lattice workspace is a file-scope device array.  Every GPU the library runs on holds its own
+// copy at its own address; `scratch` itself is only a host-side handle for hipGetSymbolAddress and
+// must never be passed to a kernel or a memset.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+static __device__ __align__(256) unsigned char scratch[RNNT_STATIC_WORKSPACE_BYTES];
+
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];  // device address of `scratch` per device ordinal
+
+// Address of the CURRENT device's copy, looked up once per device (hipGetSymbolAddress is
+// idempotent, so two threads racing through the first call store the same value).
+rnntStatus_t static_workspace(void **out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RNNT_STATUS_EXECUTION_FAILED;
+    void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return RNNT_STATUS_EXECUTION_FAILED;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return RNNT_STATUS_SUCCESS;
+}
+}  // namespace
+extern "C" {
+
+rnntStatus_t compute_rnnt_loss_static(const void *acts, void *grads, const int *labels, const int *label_lens,
+                                      const int *act_lens, int alphabet_size, int minibatch, float *costs,
+                                      rnntOptions options) {
+    size_t need = 0;
+    const rnntStatus_t q = rnnt_get_workspace_size(options.maxT, options.maxU, minibatch, &need);
+    if (q != RNNT_STATUS_SUCCESS) return q;
+    if (need > (size_t)RNNT_STATIC_WORKSPACE_BYTES) return RNNT_STATUS_STATIC_WORKSPACE_EXCEEDED;
+    void *ws = nullptr;
+    const rnntStatus_t s = static_workspace(&ws);
+    if (s != RNNT_STATUS_SUCCESS) return s;
+    // K1 and K2 write every lattice value K2 and K3 read (the workspace of the allocating entry
+    // points is uninitialised memory too), so nothing has to be cleared between calls.
+    return compute_rnnt_loss(acts, grads, labels, label_lens, act_lens, alphabet_size, minibatch, costs, ws,
+                             options);
 }
 
 rnntStatus_t rnnt_reduce_costs(const float *costs, float *loss_out, int minibatch, int reduction,
