@@ -10,10 +10,11 @@ and raises if ``rnnt_amd/lib/librnnt_mi355.so`` is missing (no fallback exists).
 from .loss import RNNTLoss, rnnt_loss, certify_inputs  # noqa: F401
 from .decode import greedy_decode, greedy_search_batch, row_argmax, row_max_logp  # noqa: F401
 from .joint import JointNet, joint_hidden  # noqa: F401
-from .parallel import ShardedRNNTLoss, balanced_assignment, shard_bounds, shard_batch  # noqa: F401
+from .parallel import (ShardedRNNTLoss, all_reduce_gradients, balanced_assignment, shard_bounds,  # noqa: F401
+                       shard_batch)
 from .train_step import GuardedStep  # noqa: F401
 
 __all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch",
-           "balanced_assignment", "JointNet", "joint_hidden", "greedy_decode", "greedy_search_batch", "row_argmax",
+           "balanced_assignment", "all_reduce_gradients", "JointNet", "joint_hidden", "greedy_decode", "greedy_search_batch", "row_argmax",
            "row_max_logp", "GuardedStep"]
 __version__ = "0.1.0"

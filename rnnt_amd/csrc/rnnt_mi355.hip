@@ -52,6 +52,14 @@ __device__ __forceinline__ RowCoord decode_row(long long r, int maxT, int U1) {
 __device__ __forceinline__ bool lens_ok(int Tb, int Ub, int maxT, int U1) {
     return Tb >= 1 && Tb <= maxT && Ub >= 0 && Ub < U1;
 }
+// log of the row's sum of exponentials given its maximum m.  A row whose maximum is +inf has no
+// log-softmax (torch.log_softmax: NaN in every element, x - inf = -inf or NaN and the sum is NaN):
+// NaN here makes lp_blank / lp_label of the node NaN, hence the utterance's cost, as upstream's CPU path.
+// (An all -inf row, m = -inf, gives log(0 + ...) with s = V after the clamp of m to 0: x - 0 = -inf,
+// exp = 0, s = 0, log = -inf and lp = -inf - (-inf) = NaN, also as torch.)
+__device__ __forceinline__ float row_log_sum(float s, float m) {
+    return m == INFINITY ? __builtin_nanf("") : __logf(s);
+}
 // Skewed lattice layout: one anti-diagonal d = t+u of one utterance is one row of US floats
 // (US = U1 rounded up to a multiple of 64, so a wave reads/writes whole aligned 256-byte rows).
 __device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US) {
@@ -263,7 +271,8 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
 #pragma unroll
             for (int i = 0; i < WPR; ++i) m = fmaxf(m, red[0][rib * WPR + i]);
         }
-        // all -inf row (or +inf max): avoid inf-inf; the result is NaN/-inf downstream as in torch
+        // all -inf row or +inf max: avoid inf-inf in the sum; torch.log_softmax returns NaN for the whole
+        // row in both cases, and so does this (`logs` below), so the cost is NaN (bin/train.py:36-41 skips it)
         const float mm = (m == -INFINITY || m == INFINITY) ? 0.0f : m;
         float s = 0.0f;
 #pragma unroll
@@ -285,7 +294,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
             for (int i = 0; i < WPR; ++i) s += red[1][rib * WPR + i];  // fixed order: reproducible
         }
         if (valid && seg == 0 && lane == 0) {
-            const float logs = __logf(s);
+            const float logs = row_log_sum(s, m);
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             L.ml[o] = make_float2(mm, logs);
             // same association as torch.log_softmax on the upstream CPU path: (x - max) - log(sum)
@@ -411,6 +420,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
             }
         }
         float m[NR], s[NR];
+        bool pinf[NR];
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             m[n] = -INFINITY;
@@ -433,6 +443,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
             for (int n = 0; n < NR; ++n) m[n] = fmaxf(m[n], __shfl_xor(m[n], off, kWave));
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
+            pinf[n] = m[n] == INFINITY;
             m[n] = (m[n] == -INFINITY || m[n] == INFINITY) ? 0.0f : m[n];  // as rnnt_k1_lse
             s[n] = 0.0f;
 #pragma unroll
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_small(
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
             if (sub == 0 && row[n].valid) {
-                const float logs = __logf(s[n]);
+                const float logs = row_log_sum(s[n], pinf[n] ? INFINITY : 0.0f);
                 const size_t o = skew_index(row[n].b, row[n].t, row[n].u, L.ND, L.US);
                 L.ml[o] = make_float2(m[n], logs);
                 L.lp[o] = make_float2((xb[n] - m[n]) - logs,
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
                 S += (red_s[i] == 0.0f) ? 0.0f : red_s[i] * __builtin_amdgcn_exp2f((safe(red_m[i]) - mm) * kLog2e);
             const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
             const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
-            const float logs = __logf(S);
+            const float logs = row_log_sum(S, MM);
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             L.ml[o] = make_float2(mm, logs);
             L.lp[o] = make_float2((DT::to_float(row[blank]) - mm) - logs, (c.u < Ub) ? (xy - mm) - logs : -INFINITY);
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
         s = wave_sum(s);
         if (lane == 0) {
             const int y = (c.u < Ub) ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
-            const float logs = __logf(s);
+            const float logs = row_log_sum(s, m);
             const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
             const float xy = (y >= 0 && y < V) ? DT::to_float(row[y]) : __builtin_nanf("");
             L.ml[o] = make_float2(mm, logs);
@@ -1210,12 +1221,16 @@ inline void record(const rnntOptions &o, int i) {
         (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[i]), static_cast<hipStream_t>(o.stream));
 }
 
-// Developer knobs for A/B runs (tools/sweep.sh); unset in production, where the defaults below are
-// the measured best on config 2 (profiles/r01_tuning.md).
+// Developer knobs for A/B runs (tools/sweep.sh builds with -DRNNT_TUNING); compiled out of the default
+// library, where the constants below are the measured best on config 2 (profiles/r01_tuning.md).
+#ifdef RNNT_TUNING  // developer build only (tools/sweep.sh): the shipped library never reads the environment
 inline int tuning_knob(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+#else
+constexpr int tuning_knob(const char *, int dflt) { return dflt; }
+#endif
 
 #define FOR_EACH_NCH(M) M(1) M(2) M(4) M(6) M(8) M(10) M(12) M(14) M(16) M(17)
 #define FOR_EACH_NCH_K3(M) M(1) M(2) M(4) M(6) M(8) M(12) M(16) M(17)

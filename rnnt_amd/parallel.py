@@ -18,7 +18,7 @@ inside K3.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -67,6 +67,48 @@ def balanced_assignment(act_lens: Sequence[int], label_lens: Sequence[int], worl
         lap, pos = divmod(k, world_size)
         parts[pos if lap % 2 == 0 else world_size - 1 - pos].append(i)
     return [sorted(p) for p in parts]
+
+
+def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None,
+                         bucket_bytes: int = 256 << 20) -> None:
+    """SUM all-reduce of the parameters' ``.grad`` across the ranks, in place — the other half of what
+    the reference's ``DataParallel`` does (``bin/train.py:241-244``: replica gradients are reduce-added
+    into the one parameter set).
+
+    SUM, not the average DistributedDataParallel takes: :class:`ShardedRNNTLoss` already divides by the
+    GLOBAL batch ('mean'), so a rank's parameter gradient is its utterances' share of the global
+    gradient and the shares add up.  (With DDP instead, multiply the loss by the world size.)
+    Gradients are packed into flat buckets of ``bucket_bytes`` per dtype so that xGMI sees a few large
+    ring all-reduces rather than one latency-bound collective per parameter; parameters a rank did not
+    touch (``.grad is None``) count as zeros, so every rank issues the same collectives.
+    """
+    params = [p for p in parameters if p.requires_grad]
+    by_dtype = {}
+    for p in params:
+        by_dtype.setdefault((p.dtype, p.device), []).append(p)
+    for (dtype, device), ps in by_dtype.items():
+        esz = torch.empty((), dtype=dtype).element_size()
+        bucket, size = [], 0
+        buckets = []
+        for p in ps:
+            if bucket and (size + p.numel()) * esz > bucket_bytes:
+                buckets.append(bucket)
+                bucket, size = [], 0
+            bucket.append(p)
+            size += p.numel()
+        if bucket:
+            buckets.append(bucket)
+        for bucket in buckets:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for p in bucket:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
 
 
 def _default_loss_fn(acts, labels, act_lens, label_lens, blank):

@@ -33,10 +33,18 @@ class GuardedStep:
         accumulation_steps: ``config.training.accumulation_steps``.
         max_grad_norm: ``config.training.max_grad_norm`` (falsy: no clipping, grad_norm is 0).
         num_gpu: ``config.training.num_gpu``; the loss is divided by it when > 1 (``:34-35``).
+            Leave it at 1 with :class:`rnnt_amd.ShardedRNNTLoss`, whose 'mean' already divides by the
+            global batch.
+        group: one-process-per-GPU training (``ShardedRNNTLoss``): pass the process group (or ``True``
+            for the default one) and every micro-batch's parameter gradients are SUM all-reduced across
+            the ranks before they reach ``.grad`` — what ``DataParallel`` did for the reference.  This
+            class calls ``torch.autograd.grad``, which fires no ``backward()`` hooks, so wrapping the
+            model in DistributedDataParallel would NOT synchronise anything here; use ``group=``.
+            The sharded loss has the same value on every rank, so all ranks skip the same batches.
     """
 
     def __init__(self, parameters: Iterable[torch.nn.Parameter], accumulation_steps: int = 1,
-                 max_grad_norm: Optional[float] = None, num_gpu: int = 1):
+                 max_grad_norm: Optional[float] = None, num_gpu: int = 1, group=None):
         self.params = [p for p in parameters if p.requires_grad]
         if not self.params:
             raise ValueError("no parameter requires a gradient")
@@ -45,6 +53,7 @@ class GuardedStep:
         self.accumulation_steps = int(accumulation_steps)
         self.max_grad_norm = float(max_grad_norm) if max_grad_norm else None
         self.num_gpu = int(num_gpu)
+        self.group = group
         dev = self.params[0].device
         self.total_loss = torch.zeros((), dtype=torch.float32, device=dev)  # as `total_loss += loss_val`
         self.skipped = torch.zeros((), dtype=torch.int64, device=dev)       # micro-batches dropped
@@ -59,6 +68,8 @@ class GuardedStep:
         finite = torch.isfinite(loss.detach())
         loss = loss / self.accumulation_steps
         grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        if self.group is not None:
+            grads = self._sum_over_ranks(grads)
         for p, g in zip(self.params, grads):
             if g is None:
                 continue
@@ -83,6 +94,25 @@ class GuardedStep:
         self.skipped += (~finite).to(torch.int64)
         self.steps += 1
         return value, grad_norm
+
+    def _sum_over_ranks(self, grads):
+        """One flat SUM all-reduce per dtype of this micro-batch's gradients (absent ones as zeros, so the
+        ranks issue identical collectives)."""
+        import torch.distributed as dist
+
+        group = None if self.group is True else self.group
+        full = [g if g is not None else torch.zeros_like(p) for p, g in zip(self.params, grads)]
+        out = list(full)
+        for dtype in {g.dtype for g in full}:
+            idx = [i for i, g in enumerate(full) if g.dtype == dtype]
+            flat = torch.cat([full[i].reshape(-1) for i in idx])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for i in idx:
+                n = full[i].numel()
+                out[i] = flat[off:off + n].view_as(full[i])
+                off += n
+        return out
 
     def average_loss(self) -> torch.Tensor:
         """``total_loss / (step + 1)`` of the reference's log line (``bin/train.py:98``), on the device."""

@@ -1,4 +1,7 @@
 """Seeded synthetic RNN-T lattices shared by the tests (numpy, CPU)."""
+import json
+import os
+
 import numpy as np
 
 
@@ -93,16 +96,33 @@ KAT2 = dict(
 )
 
 
-def assert_grad_parity(g_gpu, g_ref32, g_ref64=None, atol=1e-4):
-    """North-star bar: |g - g_cpu32| <= 1e-4 absolute.  Where |ll| is in the thousands one fp32 ulp of
+RELAXED_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                           "relaxed_grad_parity.jsonl")
+
+
+def assert_grad_parity(g_gpu, g_ref32, g_ref64=None, atol=1e-4, reduction="mean", label=""):
+    """North-star bar: |g - g_cpu32| <= 1e-4 absolute.  For reduction='mean' — the only mode the
+    reference uses (/root/reference/src/rnnt/model.py:87) — that bar is strict and nothing else is accepted.
+
+    For the UNSCALED gradients of 'sum' / 'none' on lattices where |ll| is in the thousands, one fp32 ulp of
     alpha+beta-ll is ~1e-4, so O(1) gradients of two fp32 implementations differ by ~1e-4 RELATIVE
-    (the CPU oracle's own error against float64 is that large).  In that regime, and only when a
-    float64 reference is supplied, the bar is: within 1e-4 + 1e-3|g| of the fp32 oracle AND no
-    further from float64 than twice the fp32 oracle's own distance."""
+    (the CPU oracle's own error against float64 is that large).  There, and only when a float64
+    reference is supplied, the bar is: within 1e-4 + 1e-3|g| of the fp32 oracle AND no further from
+    float64 than twice the fp32 oracle's own distance.  Every use of that branch is appended to
+    gpurun_out/relaxed_grad_parity.jsonl (copied to profiles/ per round) so the list can be audited."""
     err = np.abs(g_gpu - g_ref32)
     if err.max() <= atol:
         return
-    assert g_ref64 is not None, f"max |dg| = {err.max():.3e} > {atol}"
-    assert np.all(err <= atol + 1e-3 * np.abs(g_ref32)), f"max |dg| = {err.max():.3e}"
-    e_gpu, e_cpu = np.abs(g_gpu - g_ref64).max(), np.abs(g_ref32 - g_ref64).max()
-    assert e_gpu <= max(2 * e_cpu, atol), f"gpu {e_gpu:.3e} vs cpu-f32 {e_cpu:.3e} from float64"
+    assert reduction != "mean", f"{label}: reduction='mean' must meet the strict bar, max |dg| = {err.max():.3e} > {atol}"
+    assert g_ref64 is not None, f"{label}: max |dg| = {err.max():.3e} > {atol}"
+    e_gpu, e_cpu = float(np.abs(g_gpu - g_ref64).max()), float(np.abs(g_ref32 - g_ref64).max())
+    try:
+        os.makedirs(os.path.dirname(RELAXED_LOG), exist_ok=True)
+        with open(RELAXED_LOG, "a") as f:
+            f.write(json.dumps({"case": label, "reduction": reduction, "shape": list(g_gpu.shape),
+                                "max_abs_dg_vs_f32_oracle": float(err.max()), "max_abs_g": float(np.abs(g_ref32).max()),
+                                "gpu_vs_f64": e_gpu, "f32_oracle_vs_f64": e_cpu}) + "\n")
+    except OSError:
+        pass
+    assert np.all(err <= atol + 1e-3 * np.abs(g_ref32)), f"{label}: max |dg| = {err.max():.3e}"
+    assert e_gpu <= max(2 * e_cpu, atol), f"{label}: gpu {e_gpu:.3e} vs cpu-f32 {e_cpu:.3e} from float64"

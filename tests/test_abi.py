@@ -38,6 +38,21 @@ def test_abi_version_and_status_strings():
     assert lib.rnntGetStatusString(99) == b"unknown error"
 
 
+def test_shipped_library_does_not_read_the_environment():
+    """The RNNT_* tuning knobs exist only in the -DRNNT_TUNING developer build (make tuning)."""
+    import subprocess
+
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    assert "getenv" not in syms
+
+
+def test_lattices_wider_than_512_columns_are_a_value_error_before_any_launch():
+    acts = torch.zeros(1, 2, 514, 3)
+    with pytest.raises(ValueError, match="at most 511 labels"):
+        rnnt_amd.rnnt_loss(acts, torch.ones(1, 513, dtype=torch.int32), torch.full((1,), 2, dtype=torch.int32),
+                           torch.full((1,), 513, dtype=torch.int32))
+
+
 def test_workspace_size():
     # 6 fp32 planes of B*(ND+1)*US (+2 rows slack) + ll[B]; config 2: ND=440, US=64
     n = _lib.workspace_bytes(400, 41, 32)

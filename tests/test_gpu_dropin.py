@@ -84,17 +84,31 @@ def test_wide_lattices_multi_wave_k2(U):
     ref_loss, ref_g = oracle_mean(acts, labels, al, ll)
     assert abs(loss.item() - ref_loss[0]) <= 1e-5 * abs(ref_loss[0])
     _, g64, _ = oracle.rnnt_loss_c(acts, labels, al, ll, dtype=np.float64)
-    assert_grad_parity(a.grad.cpu().numpy(), ref_g, (g64 / 2).astype(np.float64))
+    assert_grad_parity(a.grad.cpu().numpy(), ref_g, (g64 / 2).astype(np.float64), reduction="mean",
+                       label=f"wide lattice U={U}")
 
 
 def test_too_wide_lattice_is_an_error_not_a_fault():
     import rnnt_amd
 
     a = torch.zeros((1, 2, 514, 4), device=DEV)
-    with pytest.raises(RuntimeError, match="invalid value"):
-        rnnt_amd.RNNTLoss()(a, torch.ones((1, 513), dtype=torch.int32, device=DEV),
-                            torch.tensor([2], dtype=torch.int32, device=DEV),
-                            torch.tensor([513], dtype=torch.int32, device=DEV))
+    lab = torch.ones((1, 513), dtype=torch.int32, device=DEV)
+    al, ll = (torch.tensor([v], dtype=torch.int32, device=DEV) for v in (2, 513))
+    # the operator: ValueError before any launch (a RuntimeError would send the reference's loop into its
+    # out-of-memory retry, bin/train.py:80-91)
+    with pytest.raises(ValueError, match="at most 511 labels"):
+        rnnt_amd.RNNTLoss()(a, lab, al, ll)
+    # the C ABI underneath: a status
+    from rnnt_amd import _lib
+    import ctypes
+
+    n = ctypes.c_size_t(0)
+    assert _lib.load().rnnt_get_workspace_size(2, 514, 1, ctypes.byref(n)) == 2
+    costs = torch.empty(1, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, 2, 514, _lib.DTYPE_F32, None)
+    assert _lib.load().rnnt_forward(a.data_ptr(), lab.data_ptr(), al.data_ptr(), ll.data_ptr(), 4, 1,
+                                    costs.data_ptr(), None, 0, ws.data_ptr(), opts) == 2
 
 
 def test_forward_only_and_double_backward():

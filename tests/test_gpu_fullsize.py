@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import oracle
+from cases import assert_grad_parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -101,8 +102,11 @@ def test_config2_batch_permutation():
 
 def test_config3_ragged_nan_padding():
     """BASELINE.json configs[2]: ragged B=64 (T 100-800, U 10-60); padded logits are NaN to prove masking."""
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    B = 64 if free > 130e9 else 16
+    B = 64
+    if free < 112e9:  # 52.9 GB logits + 52.9 GB gradients + temporaries
+        pytest.skip(f"CONFIG 3 NOT RUN AT FULL SIZE: needs 112 GB of device memory, {free / 1e9:.1f} GB free")
     acts, labels, al, ll = device_case(B, 800, 60, 4232, ragged=True, seed=7, nan_padding=True)
     loss, g = run(acts, labels, al, ll)
     assert bool(torch.isfinite(loss).all())
@@ -123,12 +127,10 @@ def test_config3_ragged_nan_padding():
     # 1e-4 + 1e-3 |g| on the unscaled one; and the GPU must be no further from the float64 oracle
     # than the fp32 CPU oracle is (x2 slack).
     gnp = gs.cpu().numpy()
-    assert np.all(np.abs(gnp - go_) <= 1e-4 + 1e-3 * np.abs(go_))
     _, g64, _ = oracle.rnnt_loss_c(sub.cpu().numpy(), labels[b:b + 1, :U], [T], [U], dtype=np.float64)
-    err_gpu, err_cpu = np.abs(gnp - g64).max(), np.abs(go_ - g64).max()
-    print(f"unscaled grad error vs f64: gpu {err_gpu:.2e}, cpu-f32 oracle {err_cpu:.2e}")
-    assert err_gpu <= max(2 * err_cpu, 1e-4)
-    assert float(np.abs(gnp * (0.5 / B) - go_ * (0.5 / B)).max()) <= 1e-4
+    assert_grad_parity(gnp, go_, g64, reduction="none", label=f"config3 shortest utterance T={T} U={U} unscaled")
+    # the gradient the reference's call produces ('mean' over B, grad_output 0.5): the strict bar
+    assert_grad_parity(gnp * np.float32(0.5 / B), go_ * np.float32(0.5 / B), reduction="mean", label="config3 mean")
     assert float((g[b, :T, :U + 1] - gs[0] * (0.5 / B)).abs().max()) <= 1e-7
 
 
@@ -227,3 +229,117 @@ def test_config4_sharded_equals_unsharded_bitwise_at_full_size():
     assert torch.equal(gathered, costs.detach())
     assert torch.equal(rnnt_amd.loss.reduce_costs(gathered, "mean"), mean)
     assert bool(torch.isfinite(mean).all())
+
+
+def lattice_planes(acts, labels, al, ll):
+    """rnnt_forward through the C ABI with a workspace of our own: returns (costs, ll from alpha, beta(0,0))
+    per utterance.  Layout as DESIGN.md §2: six fp32 planes of B*(ND+1)*US (+2*US) floats, node (b,t,u) at
+    (b*(ND+1) + t+u)*US + u; beta is plane 5, ll[B] follows plane 6."""
+    from rnnt_amd import _lib
+    from rnnt_amd.loss import _DTYPES
+
+    B, T, U1, V = acts.shape
+    ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=DEV)
+    costs = torch.empty(B, dtype=torch.float32, device=DEV)
+    opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, T, U1, _DTYPES[acts.dtype], None)
+    d = lambda x: torch.from_numpy(x).to(DEV)
+    lab, ald, lld = d(labels), d(al), d(ll)
+    _lib.check(_lib.load().rnnt_forward(acts.data_ptr(), lab.data_ptr(), ald.data_ptr(), lld.data_ptr(), V, B,
+                                        costs.data_ptr(), None, 0, ws.data_ptr(), opts), "rnnt_forward")
+    torch.cuda.synchronize()
+    f = ws.view(torch.float32)
+    ND, US = T + U1 - 1, (U1 + 63) // 64 * 64
+    plane = B * (ND + 1) * US + 2 * US
+    beta00 = f[5 * plane: 6 * plane][torch.arange(B, device=DEV) * (ND + 1) * US]
+    return costs.cpu().numpy(), f[6 * plane: 6 * plane + B].cpu().numpy(), beta00.cpu().numpy()
+
+
+@pytest.mark.timeout(600)
+def test_config5_full_size():
+    """BASELINE.json configs[4] AT FULL SIZE: B=16 T=1500 U=150 V=16384, bf16 logits and gradients (118.75 GB
+    each), fp32 lattice: 5.9e10-element indexing in one call, 1650 K2 steps on three waves per direction.
+    Uniform lengths as the configuration says, except the last utterance (T=1100, U=100) so that padding
+    exists.  The gradient cannot be held twice, so repeatability is checked on per-utterance checksums."""
+    B, T, U, V = 16, 1500, 150, 16384
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    need = 2 * B * T * (U + 1) * V * 2 + 20e9
+    if free < need:
+        pytest.skip(f"CONFIG 5 NOT RUN AT FULL SIZE: needs {need / 1e9:.0f} GB of device memory, "
+                    f"{free / 1e9:.1f} of {total / 1e9:.1f} GB free")
+    acts, labels, al, ll = device_case(B, T, U, V, ragged=False, seed=55, dtype=torch.bfloat16)
+    al[B - 1], ll[B - 1] = 1100, 100
+    labels[B - 1, 100:] = 0
+    acts[B - 1, 1100:] = float("nan")          # padding content must not matter
+    acts[B - 1, :, 101:] = float("nan")
+
+    def checksums(g):
+        # per utterance: sum of the raw 16-bit patterns (exact integer arithmetic), and the largest |row sum|
+        sums, worst = [], 0.0
+        for b in range(B):
+            sums.append(int(g[b].view(torch.int16).to(torch.int32).sum(dtype=torch.int64)))
+            for t0 in range(0, int(al[b]), 250):
+                rs = g[b, t0:min(t0 + 250, int(al[b])), :int(ll[b]) + 1].float().sum(-1)
+                worst = max(worst, float(rs.abs().max()))
+        return sums, worst
+
+    loss, g = run(acts, labels, al, ll)
+    assert loss.shape == (1,) and bool(torch.isfinite(loss).all())
+    assert not bool(g[B - 1, 1100:].any()) and not bool(g[B - 1, :, 101:].any())   # exact zeros in the padding
+    for b in range(0, B, 5):
+        assert bool(torch.isfinite(g[b]).all())
+    sums1, worst = checksums(g)
+    # a valid node's gradients sum to zero over V up to the bf16 rounding of 16384 stored values
+    assert worst <= 3e-3, worst
+    g_last = g[B - 1, :1100, :101].clone()
+    del g
+    loss2, g = run(acts, labels, al, ll)
+    sums2, _ = checksums(g)
+    assert torch.equal(loss, loss2) and sums1 == sums2                    # bitwise repeatable (no atomics)
+    assert torch.equal(g_last, g[B - 1, :1100, :101])
+    del g, g_last
+    torch.cuda.empty_cache()
+
+    costs, ll_alpha, beta00 = lattice_planes(acts, labels, al, ll)
+    assert np.all(np.isfinite(costs)) and np.array_equal(costs, -ll_alpha)
+    np.testing.assert_allclose(beta00, ll_alpha, rtol=1e-5)              # alpha and beta agree on the likelihood
+    s = np.float32(0)
+    for v in costs:
+        s = np.float32(s + v)
+    assert float(loss) == float(np.float32(s / np.float32(B)))           # 'mean' = index-order fp32 sum / B
+
+    # one full-length utterance and the ragged one against the CPU oracle (forward only: the oracle's
+    # gradient buffer would be another 15 GB per utterance)
+    for b in (3, B - 1):
+        Tb, Ub = int(al[b]), int(ll[b])
+        sub = acts[b, :Tb, :Ub + 1].float().cpu().numpy()[None]
+        c = oracle.rnnt_loss_c(sub, labels[b:b + 1, :Ub], [Tb], [Ub], want_grads=False)[0]
+        assert abs(float(costs[b]) - c[0]) <= 1e-5 * abs(c[0]), (b, costs[b], c[0])
+        del sub
+
+
+def test_config5_lattice_shape_small_vocab_with_gradients():
+    """T=1500, U=150 (config 5's lattice: 1650 anti-diagonals, three K2 waves per direction with the LDS
+    edge hand-off) at a vocabulary small enough for the oracle to produce gradients: costs and gradients
+    against the fp32 CPU oracle; one utterance full length, one ragged."""
+    from cases import make_case
+
+    B, T, U, V = 2, 1500, 150, 256
+    acts, labels, al, ll = make_case(B, T, U, V, seed=1500, ragged=False)
+    al[1], ll[1] = 977, 131
+    labels[1, 131:] = 0
+    a = torch.from_numpy(acts).to(DEV)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    _, g64, _ = oracle.rnnt_loss_c(acts, labels, al, ll, dtype=np.float64)
+    costs, gn = run(a, labels, al, ll, reduction="none", go=1.0)
+    np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5)
+    assert_grad_parity(gn.cpu().numpy(), g, g64, reduction="none", label="T1500 U150 V256 unscaled")
+    # |ll| is ~9e3 here, one fp32 ulp of alpha+beta-ll is 1e-3: the fp32 CPU oracle itself sits 8e-3 from
+    # float64 on the few nodes every path crosses (profiles/r02_relaxed_grad_parity.jsonl), so 1e-4 absolute
+    # is below what fp32 resolves on this lattice, for the reference's CPU path as for this one; the check
+    # above is the float64-anchored one.  'mean' is the same gradient times grad_output / B, exactly:
+    loss, gm = run(a, labels, al, ll, reduction="mean", go=1.0)
+    assert abs(float(loss) - float(np.float32(c.sum(dtype=np.float32) / 2))) <= 1e-5 * abs(float(loss))
+    assert float((gm - gn * 0.5).abs().max()) <= 1e-7
+    ca, ll_alpha, beta00 = lattice_planes(a, labels, al, ll)
+    np.testing.assert_allclose(beta00, ll_alpha, rtol=1e-5)

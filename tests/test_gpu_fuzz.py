@@ -52,7 +52,8 @@ def test_random_shape_against_oracle(seed):
     if eps == 0.0:
         _, g64, _ = oracle.rnnt_loss_c(q, labels, al, ll, blank=blank, dtype=np.float64)
         _, ref_g64 = oracle.reduce_like_upstream(c, g64, reduction, go)
-        assert_grad_parity(got_g, ref_g, ref_g64)
+        assert_grad_parity(got_g, ref_g, ref_g64, reduction=reduction,
+                           label=f"fuzz seed={seed} B={B} T={T} U={U} V={V} blank={blank}")
     else:
         assert np.all(np.abs(got_g - ref_g) <= 1e-4 + eps * np.abs(ref_g))
     for b in range(B):                                             # padding is exactly zero

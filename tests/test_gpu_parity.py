@@ -226,3 +226,40 @@ def test_nan_logit_gives_nan_loss_not_an_exception():
     assert np.isfinite(grads[0]).all()
     loss_mean, _ = run_gpu(acts, labels, al, ll, "mean")
     assert np.isnan(loss_mean[0])
+
+
+@pytest.mark.parametrize("V,dtype", [(10, torch.float32), (300, torch.float32), (4232, torch.float32),
+                                     (4233, torch.float32), (8200, torch.float32), (32768, torch.float32),
+                                     (4232, torch.float16), (40000, torch.bfloat16)])
+def test_plus_inf_logit_gives_nan_loss(V, dtype):
+    """A +inf logit (fp16 logits overflow to it at 65504) has no log-softmax: torch.log_softmax, hence the
+    upstream CPU path, returns NaN for the whole row and the cost is NaN — also when the +inf sits on a
+    logit that is neither the blank nor the label, where a finite cost with a NaN gradient would slip
+    past the reference's `torch.isnan(loss)` guard (bin/train.py:36-41) into the parameters.  Every K1
+    shape: small rows, one wave per node (aligned and not), two waves per node, the streaming kernel."""
+    acts, labels, al, ll = make_case(2, 6, 3, V, seed=47 + V, ragged=False)
+    labels = np.minimum(labels, V - 2).astype(np.int32)
+    acts[1, 2, 1, V - 1] = np.inf                     # never blank (0), never a label (< V-1)
+    ref = oracle.rnnt_loss_c(acts, labels, al, ll)[0]
+    assert np.isfinite(ref[0]) and np.isnan(ref[1])   # the CPU restatement agrees
+    loss, grads = run_gpu(acts, labels, al, ll, "none", np.ones(2, np.float32), dtype=dtype)
+    assert np.isfinite(loss[0]) and np.isnan(loss[1])
+    assert np.isfinite(grads[0]).all()
+    loss_mean, _ = run_gpu(acts, labels, al, ll, "mean", dtype=dtype)
+    assert np.isnan(loss_mean[0])
+
+
+def test_plus_inf_logit_generic_kernel():
+    """The element-granular K1 (logits whose base pointer is off a 16-byte boundary with an odd row size)."""
+    import rnnt_amd
+
+    acts, labels, al, ll = make_case(3, 5, 2, 4233, seed=78, ragged=False)
+    labels = np.minimum(labels, 4000).astype(np.int32)
+    acts[2, 1, 1, 4232] = np.inf
+    dev = torch.device("cuda:0")
+    a = torch.from_numpy(acts).to(dev)[1:]
+    assert a.data_ptr() % 16 != 0
+    loss = rnnt_amd.RNNTLoss(reduction="none")(a, torch.from_numpy(labels[1:]).to(dev),
+                                               torch.from_numpy(al[1:]).to(dev), torch.from_numpy(ll[1:]).to(dev))
+    loss = loss.cpu().numpy()
+    assert np.isfinite(loss[0]) and np.isnan(loss[1])

@@ -137,6 +137,93 @@ def test_balanced_partition_equals_unsharded_bitwise(tmp_path):
     assert sorted(seen) == list(range(B))
 
 
+class TinyTransducer(torch.nn.Module):
+    """enc/dec features -> logits [B,T,U+1,V] the way the reference's joint does (model.py:39-59)."""
+
+    def __init__(self, D=6, V=7):
+        super().__init__()
+        torch.manual_seed(3)
+        self.enc = torch.nn.Linear(D, 8)
+        self.dec = torch.nn.Embedding(V, 8)
+        self.out = torch.nn.Linear(8, V)
+        self.unused = torch.nn.Parameter(torch.zeros(2))  # never reached by the loss: .grad stays None
+
+    def forward(self, feats, tokens_with_bos):
+        h = torch.tanh(self.enc(feats).unsqueeze(2) + self.dec(tokens_with_bos).unsqueeze(1))
+        return self.out(h)
+
+
+def _training_batches(B, steps):
+    from cases import make_case
+
+    out = []
+    for k in range(steps):
+        _, labels, al, ll = make_case(B, 6, 3, 7, seed=500 + k, ragged=True)
+        feats = np.random.default_rng(600 + k).standard_normal((B, 6, 6)).astype(np.float32)
+        if k == 1:
+            feats[0, 0, 0] = np.nan  # a NaN loss: the reference skips this update (bin/train.py:36-41)
+        out.append((feats, labels, al, ll))
+    return out
+
+
+def _train(model, batches, world, rank, mode):
+    """Three optimiser steps; `mode`: 'single' (unsharded), 'helper' (loss.backward + all_reduce_gradients)
+    or 'guarded' (GuardedStep(group=True))."""
+    from rnnt_amd import GuardedStep, all_reduce_gradients
+
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    guard = GuardedStep(model.parameters(), accumulation_steps=1, max_grad_norm=5.0,
+                        group=True if mode == "guarded" else None)
+    for feats, labels, al, ll in batches:
+        B = feats.shape[0]
+        full = [torch.from_numpy(x) for x in (feats, labels, al, ll)]
+        lo, hi = shard_bounds(B, world, rank) if world > 1 else (0, B)
+        f, lab, alr, llr = (x[lo:hi] for x in full)
+        logits = model(f, torch.nn.functional.pad(lab.long(), [1, 0, 0, 0], value=0))
+        if world > 1:
+            loss = ShardedRNNTLoss(loss_fn=oracle_loss_fn)(logits, lab, alr, llr, global_batch=B)
+        else:
+            c = oracle_loss_fn(logits, lab, alr, llr, 0)
+            loss = ordered_reduce(c, "mean") + (c.sum() - c.sum().detach()) / B
+        if mode == "helper":
+            if bool(torch.isfinite(loss).all()):
+                loss.backward()
+                all_reduce_gradients(model.parameters())
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        else:
+            guard(loss)
+        opt.step()
+        opt.zero_grad()
+    return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def training_worker(rank, world, port, mode, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = _train(TinyTransducer(), _training_batches(5, 3), world, rank, mode)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **params)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["helper", "guarded"])
+def test_two_ranks_train_like_one(tmp_path, mode):
+    """sharded loss + SUM all-reduce of the parameter gradients reproduces the
+    unsharded training run (what DataParallel's reduce-add gave the reference), including a skipped
+    NaN batch and gradient clipping; both ranks end with the same parameters."""
+    world = 2
+    mp.spawn(training_worker, args=(world, free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    ref = _train(TinyTransducer(), _training_batches(5, 3), 1, 0, "single")
+    start = {k: v.detach().numpy() for k, v in TinyTransducer().state_dict().items()}
+    assert any(np.abs(ref[k] - start[k]).max() > 1e-3 for k in ref)      # training moved the parameters
+    r0, r1 = (np.load(tmp_path / f"r{r}.npz") for r in range(world))
+    for k in ref:
+        np.testing.assert_array_equal(r0[k], r1[k])                       # replicas stay in step
+        np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=2e-6)      # summation order differs
+
+
 def test_balanced_assignment_balances_lattice_work():
     rng = np.random.default_rng(5)
     al = rng.integers(100, 801, size=64)
