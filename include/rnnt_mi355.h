@@ -169,6 +169,27 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
                                         void *workspace, void *stream);
 
 /*
+ * ---- the joint's output projection fused with the loss's first pass ----------
+ *
+ * Replaces the pair  logits = Linear(H -> V)(hidden)  (/root/reference/src/rnnt/model.py:17,59) and the
+ * forward half of the loss on those logits (model.py:116) for 16-bit operands: ONE kernel multiplies
+ * hidden [B*T*U1, H] by weight [V, H] (nn.Linear's layout) + bias [V] (fp32) on the matrix cores, writes the
+ * logits once to logits_out [B, T, U1, V] (rounded to `options.dtype`; rnnt_backward reads them) and keeps
+ * each lattice node's max / sum-exp / blank and label log-probabilities without ever re-reading the logits:
+ * the K1 pass of rnnt_forward disappears.  K2 and the cost reduction follow as in rnnt_forward; costs,
+ * loss_out, reduction and workspace as there.  The softmax statistics are those of the ROUNDED logits, so
+ * rnnt_backward(logits_out, ...) afterwards is exactly the backward of rnnt_forward(logits_out, ...).
+ * options.dtype: RNNT_DTYPE_BF16 or RNNT_DTYPE_F16 (fp32 accumulation; fp32 operands are not taken: the
+ * fp32 matrix rate is 1/16 of the 16-bit one); hidden_size: 128, 256 or 512; hidden and weight
+ * 16-byte aligned.  INVALID_VALUE otherwise.
+ */
+rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, const float *bias,
+                                     void *logits_out, const int *labels, const int *act_lens,
+                                     const int *label_lens, int hidden_size, int alphabet_size,
+                                     int minibatch, float *costs, float *loss_out, int reduction,
+                                     void *workspace, rnntOptions options);
+
+/*
  * ---- greedy decoding --------------------------------------------------------
  * out[r] = first index of the maximum of row r of x[rows, V] (a NaN counts as the maximum: torch.argmax's
  * conventions).  Replaces the per-frame softmax -> argmax of the reference's greedy loop

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "compute_rnnt_loss",
     "compute_rnnt_loss_static",
     "rnnt_reduce_costs",
+    "rnnt_joint_loss_forward",
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
@@ -115,6 +116,9 @@ def load() -> ctypes.CDLL:
         lib.compute_rnnt_loss_static.restype = ctypes.c_int
         lib.rnnt_reduce_costs.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_reduce_costs.restype = ctypes.c_int
+        lib.rnnt_joint_loss_forward.argtypes = [vp, vp, fp, vp, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                fp, fp, ctypes.c_int, vp, RnntOptions]
+        lib.rnnt_joint_loss_forward.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_joint_hidden_forward.restype = ctypes.c_int

@@ -26,6 +26,7 @@
 
 #include "../../include/rnnt_mi355.h"
 #include "elem_types.h"
+#include "lattice.h"
 
 namespace {
 
@@ -34,37 +35,6 @@ using namespace rnnt_mi355_detail;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kAbiVersion = 1;
-
-struct RowCoord {
-    int b, t, u;
-};
-__device__ __forceinline__ RowCoord decode_row(long long r, int maxT, int U1) {
-    const long long per_b = (long long)maxT * U1;
-    RowCoord c;
-    c.b = (int)(r / per_b);
-    const int rem = (int)(r - (long long)c.b * per_b);
-    c.t = rem / U1;
-    c.u = rem - c.t * U1;
-    return c;
-}
-// Lengths that do not fit the logits tensor never reach an address computation: the utterance is
-// treated as all padding by K1/K3 and K2 reports a NaN cost (rnnt_mi355.h: "NaN, not an error").
-__device__ __forceinline__ bool lens_ok(int Tb, int Ub, int maxT, int U1) {
-    return Tb >= 1 && Tb <= maxT && Ub >= 0 && Ub < U1;
-}
-// log of the row's sum of exponentials given its maximum m.  A row whose maximum is +inf has no
-// log-softmax (torch.log_softmax: NaN in every element, x - inf = -inf or NaN and the sum is NaN):
-// NaN here makes lp_blank / lp_label of the node NaN, hence the utterance's cost, as upstream's CPU path.
-// (An all -inf row, m = -inf, gives log(0 + ...) with s = V after the clamp of m to 0: x - 0 = -inf,
-// exp = 0, s = 0, log = -inf and lp = -inf - (-inf) = NaN, also as torch.)
-__device__ __forceinline__ float row_log_sum(float s, float m) {
-    return m == INFINITY ? __builtin_nanf("") : __logf(s);
-}
-// Skewed lattice layout: one anti-diagonal d = t+u of one utterance is one row of US floats
-// (US = U1 rounded up to a multiple of 64, so a wave reads/writes whole aligned 256-byte rows).
-__device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US) {
-    return ((size_t)b * (ND + 1) + (size_t)(t + u)) * US + u;  // +1: K2's junk row
-}
 
 // Word 3 of a raw (stride 0, byte-offset) buffer descriptor on gfx90a/gfx942/gfx950: 32-bit data
 // format, offsets checked against num_records; and the `nt` bit of a buffer load's cache policy.
@@ -127,17 +97,6 @@ __device__ __forceinline__ void store_inside_row(const u32x4 &v, u32x4 *p, int f
             if ((unsigned)(first + j) < (unsigned)V) o[j] = (unsigned short)(w[j >> 1] >> (16 * (j & 1)));
     }
 }
-
-struct Lattice {      // device pointers into the workspace
-    float2 *ml;       // {max_v x_v, log sum_v exp(x_v - max)} per node, kept apart: lse = m + l would
-                      // round to ulp(|m|) and cost K3 that much relative accuracy on offset logits
-    float2 *lp;       // {lp_blank, lp_label} per node
-    float *alpha;
-    float *beta;
-    float *ll;        // [B] forward log-likelihood
-    int ND;           // anti-diagonals per utterance = maxT + maxU - 1
-    int US;           // row stride of the skewed layout
-};
 
 // ---------------------------------------------------------------------------------------------
 // K1: log-softmax denominators; keep blank and next-label log-probs.  
@@ -1397,6 +1356,25 @@ rnntStatus_t launch_k2(const int *act_lens, const int *label_lens, int B, float 
 
 }  // namespace
 
+namespace rnnt_mi355_detail {
+// Everything of the forward pass after the lattice planes {max, log-sum} and {lp_blank, lp_label} are
+// written: stage event 1, K2, the cost reduction, stage event 2.
+rnntStatus_t launch_lattice_and_costs(const int *act_lens, const int *label_lens, int B, float *costs,
+                                      float *loss_out, int reduction, const Lattice &L, const rnntOptions &o) {
+    record(o, 1);
+    const rnntStatus_t s = launch_k2(act_lens, label_lens, B, costs, L, o);
+    if (s != RNNT_STATUS_SUCCESS) return s;
+    if (loss_out) {
+        hipLaunchKernelGGL(rnnt_reduce_costs_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(o.stream), costs,
+                           loss_out, B, reduction);
+        if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    }
+    record(o, 2);
+    return RNNT_STATUS_SUCCESS;
+}
+Lattice carve_workspace(void *ws, int maxT, int maxU, int B) { return carve(ws, maxT, maxU, B); }
+}  // namespace rnnt_mi355_detail
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -1450,16 +1428,7 @@ rnntStatus_t rnnt_forward(const void *acts, const int *labels, const int *act_le
             s = launch_k1<F16>(acts, labels, act_lens, label_lens, alphabet_size, minibatch, w, options);
     }
     if (s != RNNT_STATUS_SUCCESS) return s;
-    record(options, 1);
-    s = launch_k2(act_lens, label_lens, minibatch, costs, w, options);
-    if (s != RNNT_STATUS_SUCCESS) return s;
-    if (loss_out) {
-        hipLaunchKernelGGL(rnnt_reduce_costs_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(options.stream),
-                           costs, loss_out, minibatch, reduction);
-        if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
-    }
-    record(options, 2);
-    return RNNT_STATUS_SUCCESS;
+    return launch_lattice_and_costs(act_lens, label_lens, minibatch, costs, loss_out, reduction, w, options);
 }
 
 rnntStatus_t rnnt_backward(const void *acts, void *grads, const int *labels, const int *act_lens,

@@ -1,0 +1,150 @@
+"""``FusedJointLoss`` — the joint network's output projection and the RNN-T loss as one operator
+(SURVEY.md §8f rank 1).
+
+The reference runs ``Linear(inner_dim -> vocab)`` as the last layer of ``JointNet.mlp``
+(/root/reference/src/rnnt/model.py:14-18, applied at :59) and hands the ``[B,T,U+1,V]`` logits to
+``RNNTLoss`` (:116).  For 16-bit operands this module does both with ``rnnt_joint_loss_forward``
+(include/rnnt_mi355.h): one MFMA kernel writes the logits once and produces the log-softmax statistics
+in its epilogue, so the loss's first pass over the logits (K1) does not exist.  Backward is K3 on the
+stored logits followed by the two plain library GEMMs of a Linear layer's backward.
+
+This is an EXTENSION next to the drop-in, not part of it: its inputs are the hidden activations and the
+projection's parameters, not logits.  No CPU path, no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .loss import _DTYPES, _REDUCTIONS, MAX_LATTICE_COLUMNS
+
+SUPPORTED_HIDDEN = (128, 256, 512)
+
+
+class _FusedJointLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction):
+        lib = _lib.load()
+        B, T, U1, H = hidden.shape
+        V = weight.shape[0]
+        dev = hidden.device
+        red = _REDUCTIONS[reduction]
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            bias32 = bias.detach().to(torch.float32).contiguous()
+            logits = torch.empty((B, T, U1, V), dtype=hidden.dtype, device=dev)
+            ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=dev)
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            loss = torch.empty(B if red == _lib.REDUCTION_NONE else 1, dtype=torch.float32, device=dev)
+            opts = _lib.RnntOptions(stream, int(blank), T, U1, _DTYPES[hidden.dtype], None)
+            _lib.check(lib.rnnt_joint_loss_forward(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
+                                                   logits.data_ptr(), labels.data_ptr(), act_lens.data_ptr(),
+                                                   label_lens.data_ptr(), H, V, B, costs.data_ptr(),
+                                                   loss.data_ptr(), red, ws.data_ptr(), opts),
+                       "rnnt_joint_loss_forward")
+        ctx.save_for_backward(hidden, weight, logits, labels, act_lens, label_lens, ws)
+        ctx.blank = int(blank)
+        ctx.reduction = red
+        ctx.bias_dtype = bias.dtype
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        hidden, weight, logits, labels, act_lens, label_lens, ws = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, U1, V = logits.shape
+        H = hidden.shape[-1]
+        dev = logits.device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            go = grad_output.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+            if ctx.reduction == _lib.REDUCTION_NONE:
+                stride, scale = 1, 1.0
+            else:
+                stride, scale = 0, (1.0 / B if ctx.reduction == _lib.REDUCTION_MEAN else 1.0)
+            g_logits = torch.empty_like(logits)
+            opts = _lib.RnntOptions(stream, ctx.blank, T, U1, _DTYPES[logits.dtype], None)
+            _lib.check(lib.rnnt_backward(logits.data_ptr(), g_logits.data_ptr(), labels.data_ptr(),
+                                         act_lens.data_ptr(), label_lens.data_ptr(), V, B, go.data_ptr(), stride,
+                                         ctypes.c_float(scale), ws.data_ptr(), opts), "rnnt_backward")
+            g2 = g_logits.view(-1, V)
+            h2 = hidden.reshape(-1, H)
+            g_hidden = g_weight = g_bias = None
+            if ctx.needs_input_grad[0]:
+                g_hidden = torch.mm(g2, weight).view_as(hidden)        # plain library GEMMs (hipBLASLt)
+            if ctx.needs_input_grad[1]:
+                g_weight = torch.mm(g2.t(), h2)
+            if ctx.needs_input_grad[2]:
+                g_bias = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        return g_hidden, g_weight, g_bias, None, None, None, None, None
+
+
+def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean"):
+    """``RNNTLoss(blank, reduction)(hidden @ weight.T + bias, labels, act_lens, label_lens)`` in one pass.
+
+    Args:
+        hidden: ``[B, T, U+1, H]`` bf16 or fp16, contiguous: what ``JointNet``'s ``Tanh`` returns
+            (``rnnt_amd.joint_hidden``); ``H`` in ``SUPPORTED_HIDDEN``.
+        weight, bias: the parameters of ``Linear(H -> V)`` (``mlp.2`` of the reference's ``JointNet``);
+            weight in ``hidden``'s dtype, ``[V, H]`` contiguous.
+        labels, act_lens, label_lens, blank, reduction: as :func:`rnnt_amd.rnnt_loss`.
+    """
+    if reduction not in _REDUCTIONS:
+        raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
+    if hidden.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("fused_joint_loss takes bfloat16 or float16 activations (fp32: use JointNet + RNNTLoss; "
+                        "the fp32 matrix rate of the MI355X is 1/16 of the 16-bit one)")
+    if weight.dtype is not hidden.dtype:
+        raise TypeError("weight must have hidden's dtype")
+    if hidden.dim() != 4 or weight.dim() != 2 or bias.dim() != 1:
+        raise ValueError("hidden must be 4D, weight 2D, bias 1D")
+    if not hidden.is_cuda:
+        raise RuntimeError("rnnt_amd.fused_joint_loss computes on MI355X (ROCm device tensors) only; "
+                           "there is no CPU path or PyTorch fallback in this package.")
+    B, T, U1, H = hidden.shape
+    V = weight.shape[0]
+    if weight.shape[1] != H or bias.shape[0] != V:
+        raise ValueError("weight must be [V, H] and bias [V]")
+    if H not in SUPPORTED_HIDDEN:
+        raise ValueError(f"fused_joint_loss supports inner sizes {SUPPORTED_HIDDEN}, got {H}")
+    if V < 64:
+        raise ValueError(f"fused_joint_loss needs a vocabulary of at least 64 entries (one tile), got {V}")
+    if U1 > MAX_LATTICE_COLUMNS:
+        raise ValueError(f"rnnt_amd supports at most {MAX_LATTICE_COLUMNS - 1} labels per utterance")
+    for name, t in (("labels", labels), ("lengths", act_lens), ("label_lengths", label_lens)):
+        if t.dtype is not torch.int32:
+            raise TypeError(f"{name} must be torch.int32")
+        if t.device != hidden.device:
+            raise RuntimeError(f"{name} must be on the same device as hidden")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if labels.dim() != 2 or labels.shape[0] != B or labels.shape[1] != U1 - 1:
+        raise ValueError("Output length mismatch")
+    if act_lens.shape != (B,) or label_lens.shape != (B,):
+        raise ValueError("must have a length per example.")
+    if not (0 <= int(blank) < V):
+        raise ValueError("blank label out of range")
+    if not hidden.is_contiguous():
+        hidden = hidden.contiguous()
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction)
+
+
+class FusedJointLoss(torch.nn.Module):
+    """``Linear(H -> V)`` of the joint network + ``RNNTLoss`` as one module; owns no parameters: pass the
+    projection (``joint.mlp[2]`` of the reference's or this package's ``JointNet``) at call time."""
+
+    def __init__(self, blank: int = 0, reduction: str = "mean"):
+        super().__init__()
+        if reduction not in _REDUCTIONS:
+            raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
+        self.blank = blank
+        self.reduction = reduction
+
+    def forward(self, hidden, projection: torch.nn.Linear, labels, act_lens, label_lens):
+        return fused_joint_loss(hidden, projection.weight, projection.bias, labels, act_lens, label_lens,
+                                self.blank, self.reduction)
