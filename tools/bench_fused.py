@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Joint projection + RNN-T loss, fused against unfused, in one run.
+
+    python tools/bench_fused.py [--shape B,T,U,V,H] [--dtype bf16|f16] [--reps N] [--out file.json]
+
+forward   unfused: library GEMM (torch.addmm -> hipBLASLt) writes the logits, rnnt_forward reads them (K1) + K2
+          fused:   rnnt_joint_loss_forward (MFMA GEMM with K1 as its epilogue) + K2
+fwd+bwd   both paths then run K3 and the two library GEMMs of the Linear's backward (dH, dW) + the bias sum.
+
+Device time from hipEvents on the launch stream, median of --reps after warm-up; one JSON object.
+profiles/r02_bench_fused.json is a run of this at BASELINE config 2's lattice (B32 T400 U40 V4232, H=512, bf16).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def median_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="32,400,40,4232,512")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--reps", type=int, default=15)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import rnnt_amd
+
+    B, T, U, V, H = (int(x) for x in args.shape.split(","))
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    hidden = torch.tanh(torch.randn(B, T, U + 1, H, device=dev, generator=g)).to(dt).requires_grad_(True)
+    proj = torch.nn.Linear(H, V).to(dev).to(dt)
+    labels = torch.randint(1, V, (B, U), device=dev, dtype=torch.int32, generator=g)
+    al = torch.full((B,), T, device=dev, dtype=torch.int32)
+    ll = torch.full((B,), U, device=dev, dtype=torch.int32)
+    crit = rnnt_amd.RNNTLoss(check_lengths=False)
+    fused = rnnt_amd.FusedJointLoss()
+    go = torch.full((1,), 0.5, device=dev)
+
+    def clear():
+        hidden.grad = None
+        proj.weight.grad = None
+        proj.bias.grad = None
+
+    def unfused_fwd():
+        with torch.no_grad():
+            return crit(torch.nn.functional.linear(hidden, proj.weight, proj.bias), labels, al, ll)
+
+    def fused_fwd():
+        with torch.no_grad():
+            return fused(hidden, proj, labels, al, ll)
+
+    def unfused_step():
+        clear()
+        crit(torch.nn.functional.linear(hidden, proj.weight, proj.bias), labels, al, ll).backward(go)
+
+    def fused_step():
+        clear()
+        fused(hidden, proj, labels, al, ll).backward(go)
+
+    L = B * T * (U + 1)
+    flop = 2.0 * L * H * V
+    res = {
+        "shape": dict(B=B, T=T, U=U, V=V, H=H, nodes=L), "dtype": args.dtype, "device": torch.cuda.get_device_name(0),
+        "gemm_flop": flop,
+        "loss_fused": float(fused_fwd()), "loss_unfused": float(unfused_fwd()),
+        "forward_ms": {"unfused (library GEMM + K1 + K2)": round(median_ms(unfused_fwd, args.reps), 4),
+                       "fused (MFMA GEMM with K1 epilogue + K2)": round(median_ms(fused_fwd, args.reps), 4)},
+        "forward_backward_ms": {"unfused": round(median_ms(unfused_step, args.reps), 4),
+                                "fused": round(median_ms(fused_step, args.reps), 4)},
+    }
+    f = res["forward_ms"]
+    res["forward_speedup"] = round(f["unfused (library GEMM + K1 + K2)"] / f["fused (MFMA GEMM with K1 epilogue + K2)"], 3)
+    res["forward_backward_speedup"] = round(res["forward_backward_ms"]["unfused"] / res["forward_backward_ms"]["fused"], 3)
+    res["fused_forward_TFLOPs"] = round(flop / (f["fused (MFMA GEMM with K1 epilogue + K2)"] * 1e-3) / 1e12, 1)
+    out = json.dumps(res, indent=1)
+    print(out)
+    if args.out:
+        with open(args.out, "w") as fh:
+            fh.write(out + "\n")
+
+
+if __name__ == "__main__":
+    main()
