@@ -4,8 +4,11 @@ Follows ``decode`` inside ``Transducer.recognize`` (/root/reference/src/rnnt/mod
 line with stock torch ops: start the decoder on token 0 (:141,148); per frame evaluate the joint on
 the 1-D states (:151), softmax, argmax, ``.item()`` (:152-154); on a non-blank prediction append it
 and step the decoder (:156-163).  ``joint_fn(enc_vec, dec_vec) -> logits[V]`` is the reference's
-``JointNet`` evaluation path (``oracle.joint_oracle`` restates its layers).  PARITY UNPINNED: the
-reference holds no decoding fixtures.  Also returns the smallest top-2 probability margin met, so a
+``JointNet`` evaluation path (``oracle.joint_oracle`` restates its layers).  PINNED to the reference's own
+code: tests/golden/make_ref_fixtures.py runs ``Transducer.recognize`` on a seeded tiny transducer in the
+build container and writes its token lists, with the encoder states and the decoder's and joint's
+parameters, to tests/golden/ref_recognize.npz; tests/test_joint_oracle.py holds this loop to them (the
+batched search below stays unpinned).  Also returns the smallest top-2 probability margin met, so a
 test can tell a genuine disagreement from an argmax tie at rounding level.
 """
 from __future__ import annotations

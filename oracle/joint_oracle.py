@@ -5,9 +5,11 @@ step with stock torch CPU ops: unsqueeze (:40-41), repeat over U+1 and T (:47-50
 (:54) or add (:44), then ``Linear -> Tanh -> Linear`` (:14-18, :59).  Only ``tests/`` may import
 this; the product (``rnnt_amd/joint.py``) never does.
 
-PARITY UNPINNED: the reference has no tests or fixtures for its joint network, and its module
-cannot be imported here (``src/rnnt/model.py`` needs the absent ``editdistance`` and
-``warprnnt_pytorch`` packages).  The restatement uses the very torch ops the reference calls.
+PINNED to the reference's own code: tests/golden/make_ref_fixtures.py imports the reference's
+``JointNet`` in the build container (its two absent, unrelated imports stubbed), runs it in float64 for
+``concat`` and ``sum`` and writes inputs, parameters, logits and autograd gradients to
+tests/golden/ref_joint_*.npz; tests/test_joint_oracle.py holds this restatement to those within 1e-12.
+(The reference itself has no tests or fixtures for its joint network.)
 """
 from __future__ import annotations
 

@@ -1,7 +1,10 @@
 """GPU tests for the greedy-decoding widening: rnnt_row_argmax against
 torch.argmax, and rnnt_amd.greedy_decode against the restated reference loop (oracle/decode_oracle.py)
 run with the same modules on the same device.  Token sequences must be identical whenever the
-reference's own top-2 margin is above rounding level (1e-5) at every step.  PARITY UNPINNED."""
+reference's own top-2 margin is above rounding level (1e-5) at every step.  The per-utterance loop is pinned
+to the reference's own Transducer.recognize by tests/golden/ref_recognize.npz
+(test_greedy_decode_reproduces_reference_recognize); the batched search stays PARITY UNPINNED (the
+reference's own code raises on that path as shipped, see oracle/decode_oracle.py)."""
 import pytest
 import torch
 import torch.nn as nn
@@ -71,6 +74,22 @@ def test_greedy_decode_equals_reference_loop(seed, window):
         assert got == ref
     else:                            # an argmax tie at rounding level somewhere: compare up to it
         pytest.skip(f"reference top-2 margin {margin:.2e} is at rounding level")
+
+
+@pytest.mark.parametrize("window", [1, 8, 32])
+def test_greedy_decode_reproduces_reference_recognize(window):
+    """rnnt_amd.greedy_decode with the fixture's decoder and joint parameters against the token lists the
+    REFERENCE'S OWN Transducer.recognize (model.py:135-172) returned for the same encoder states."""
+    import rnnt_amd
+    from ref_fixtures import recognize_case
+
+    enc, lengths, tokens, decoder, jp, margin = recognize_case()
+    assert margin > 1e-3
+    joint = rnnt_amd.JointNet(jp[0].shape[1], jp[0].shape[0], jp[2].shape[0])
+    joint.load_state_dict(dict(zip(("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"), jp)))
+    joint, decoder, enc = joint.to(DEV), decoder.to(DEV), enc.to(DEV)
+    for i, want in enumerate(tokens):
+        assert rnnt_amd.greedy_decode(enc[i], lengths[i], decoder, joint, window=window) == want, i
 
 
 def test_greedy_decode_all_blank_and_argument_checks():

@@ -12,7 +12,7 @@ The operator is checked in its two halves, with the intermediate (the logits it 
   STORED, at the loss's own tolerances (north_star): costs <= 1e-5 relative, gradients within
   1e-4 + one rounding step of the dtype.
 
-PARITY UNPINNED for both oracles (oracle/__init__.py, oracle/joint_oracle.py).
+The loss oracle is PARITY UNPINNED (oracle/__init__.py); the joint's restatement is pinned by tests/golden/ref_joint_*.npz.
 """
 import ctypes
 

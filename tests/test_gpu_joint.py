@@ -5,7 +5,8 @@ Tolerances, fp32: hidden <= 1e-6 absolute (|tanh| <= 1; the GPU uses the device 
 torch's), logits <= 2e-5 absolute at |logit| ~ 10, gradients <= 1e-5 relative to the largest
 reference entry of the same tensor (sums of up to T*(U+1)*B fp32 terms in a different order).
 bf16/fp16: the result must equal the float64 answer rounded to the dtype within 1 ulp-ish
-(2^-8 / 2^-11 relative).  PARITY UNPINNED (see oracle/joint_oracle.py).
+(2^-8 / 2^-11 relative).  Pinned to the reference's own JointNet by tests/golden/ref_joint_*.npz
+(test_jointnet_module_against_reference_fixture; tests/golden/make_ref_fixtures.py wrote them).
 """
 import numpy as np
 import pytest
@@ -112,6 +113,30 @@ def test_jointnet_module_against_reference_restatement(joint):
     # pre-unsqueezed 4-D states (model.py:46-50) take the same path
     out4 = net(e.detach().unsqueeze(2), d.detach().unsqueeze(1))
     assert torch.equal(out4, out.detach())
+
+
+@pytest.mark.parametrize("kind", ["concat", "sum"])
+def test_jointnet_module_against_reference_fixture(kind):
+    """rnnt_amd.JointNet with the fixture's parameters against what the REFERENCE'S OWN JointNet
+    (model.py:20-63, float64) produced for the same states: logits and every gradient."""
+    import rnnt_amd
+    from ref_fixtures import joint_case
+
+    c = joint_case(kind)
+    nin, inner, V = c["params"][0].shape[1], c["params"][0].shape[0], c["params"][2].shape[0]
+    net = rnnt_amd.JointNet(nin, inner, V, joint=kind)
+    net.load_state_dict({n: p.float() for n, p in zip(c["names"], c["params"])})
+    net = net.to(DEV)
+    e = c["enc"].float().to(DEV).requires_grad_(True)
+    d = c["dec"].float().to(DEV).requires_grad_(True)
+    out = net(e, d)
+    (out * c["go"].float().to(DEV)).sum().backward()
+    assert (out.detach().cpu().double() - c["logits"]).abs().max() <= 2e-5
+    assert rel_to_max(e.grad.cpu().double(), c["grad_enc"]) <= 1e-5
+    assert rel_to_max(d.grad.cpu().double(), c["grad_dec"]) <= 1e-5
+    got = dict(net.named_parameters())
+    for n, g in zip(c["names"], c["grads"]):
+        assert rel_to_max(got[n].grad.cpu().double(), g) <= 1e-5, n
 
 
 def test_joint_then_loss_end_to_end_against_oracles():

@@ -56,3 +56,40 @@ def test_joint_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.rnnt_joint_hidden_workspace_size(0, 400, 41, 512, ctypes.byref(n)) != 0
     assert lib.rnnt_joint_hidden_forward(None, None, None, 1, 1, 1, 1, 0, None) != 0
     assert lib.rnnt_joint_hidden_backward(None, None, None, None, 1, 1, 1, 1, 0, None, None) != 0
+
+
+@pytest.mark.parametrize("kind", ["concat", "sum"])
+def test_restatement_reproduces_the_reference_joint(kind):
+    """oracle.joint_oracle against the REFERENCE'S OWN JointNet (model.py:20-63) run in float64 by
+    tests/golden/make_ref_fixtures.py: logits and every gradient, to float64 rounding."""
+    from ref_fixtures import joint_case
+
+    c = joint_case(kind)
+    enc, dec = c["enc"].clone().requires_grad_(True), c["dec"].clone().requires_grad_(True)
+    params = [p.clone().requires_grad_(True) for p in c["params"]]
+    logits = joint_logits(enc, dec, *params, joint=kind)
+    assert logits.shape == c["logits"].shape
+    assert (logits.detach() - c["logits"]).abs().max() <= 1e-13
+    (logits * c["go"]).sum().backward()
+    assert (enc.grad - c["grad_enc"]).abs().max() <= 1e-12
+    assert (dec.grad - c["grad_dec"]).abs().max() <= 1e-12
+    for p, g, name in zip(params, c["grads"], c["names"]):
+        assert (p.grad - g).abs().max() <= 1e-12, name
+
+
+def test_restated_greedy_loop_reproduces_the_reference_recognize():
+    """oracle.decode_oracle.greedy_decode_reference against the token lists Transducer.recognize
+    (model.py:135-172) returned for the fixture's encoder states and parameters; the decoder is rebuilt
+    from the fixture's weights with stock torch layers, the joint is oracle.joint_oracle."""
+    from oracle.decode_oracle import greedy_decode_reference
+    from ref_fixtures import recognize_case
+
+    enc, lengths, tokens, decoder, jp, margin = recognize_case()
+    assert margin > 1e-3                  # every argmax in the fixture is far from a tie
+    assert [len(t) for t in tokens] == [21, 17, 9]
+    for i, want in enumerate(tokens):
+        got, m = greedy_decode_reference(
+            enc[i], lengths[i], decoder,
+            lambda e, d: joint_logits(e.view(1, 1, -1), d.view(1, 1, -1), *jp).view(-1))
+        assert got == want, i
+        assert m >= margin * 0.99
