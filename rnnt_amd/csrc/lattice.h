@@ -39,6 +39,15 @@ __device__ __forceinline__ size_t skew_index(int b, int t, int u, int ND, int US
     return ((size_t)b * (ND + 1) + (size_t)(t + u)) * US + u;  // +1: K2's junk row
 }
 
+// One utterance's slice of the COMPACTED node order K1 walks: the nodes inside the utterances' lattices only,
+// utterance by utterance, frame by frame, label position fastest — the order they have in memory with the
+// padding left out.  Written by rnnt_node_spans from the length tensors on the device (the host never reads them).
+struct NodeSpan {
+    long long first;  // compacted index of the utterance's node (0, 0); entry [B] holds the total
+    int Tb;           // frames; 0 for an utterance whose lengths do not fit the tensor (it has no nodes)
+    int Ub1;          // label positions per frame, U_b + 1 (1 where Tb = 0, so that it can divide)
+};
+
 struct Lattice {      // device pointers into the workspace
     float2 *ml;       // {max_v x_v, log sum_v exp(x_v - max)} per node, kept apart: lse = m + l would
                       // round to ulp(|m|) and cost K3 that much relative accuracy on offset logits
@@ -46,6 +55,7 @@ struct Lattice {      // device pointers into the workspace
     float *alpha;
     float *beta;
     float *ll;        // [B] forward log-likelihood
+    NodeSpan *spans;  // [B + 1], see above
     int ND;           // anti-diagonals per utterance = maxT + maxU - 1
     int US;           // row stride of the skewed layout
 };

@@ -144,6 +144,87 @@ __device__ __forceinline__ void loads_issued(u32x4 (&raw)[N]) {
     for (int k = 0; k < N; ++k) asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compacted node order for K1.  A ragged batch (config 3: T 100-800, U 10-60 in a tensor cut for 800 x 61)
+// has two thirds of its rows in padding; dealt one node per wave in MEMORY order, two thirds of K1's
+// workgroups found nothing to read and left, and the bytes in flight thinned out (5.9 TB/s against 6.9 on a
+// uniform batch).  K1 therefore walks the nodes INSIDE the lattices only: one wave of rnnt_node_spans turns the
+// length tensors into per-utterance prefix offsets on the device, and K1 maps its node counter through them,
+// so consecutive workgroups stream consecutive valid rows and the surplus workgroups form an empty tail.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rnnt_node_spans(const int *__restrict__ act_lens,
+                                                      const int *__restrict__ label_lens, int B, int maxT,
+                                                      int U1, NodeSpan *__restrict__ spans) {
+    const int lane = threadIdx.x;
+    long long carry = 0;
+    for (int b0 = 0; b0 < B; b0 += kWave) {
+        const int b = b0 + lane;
+        int Tb = 0, Ub1 = 1;
+        if (b < B) {
+            const int t = act_lens[b], u = label_lens[b];
+            if (lens_ok(t, u, maxT, U1)) {
+                Tb = t;
+                Ub1 = u + 1;
+            }
+        }
+        const long long n = (long long)Tb * Ub1;
+        long long inc = n;  // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (b < B) {
+            NodeSpan e;
+            e.first = carry + inc - n;
+            e.Tb = Tb;
+            e.Ub1 = Ub1;
+            spans[b] = e;
+        }
+        carry += __shfl(inc, kWave - 1);
+    }
+    if (lane == 0) {
+        NodeSpan e;
+        e.first = carry;
+        e.Tb = 0;
+        e.Ub1 = 1;
+        spans[B] = e;
+    }
+}
+
+struct Node {
+    int b, t, u;  // position
+    int Tb, Ub;   // lengths of its utterance
+};
+// Node number k < total (wave-uniform) of the compacted order.  The search starts at utterance k / (maxT*U1)
+// — no utterance holds more nodes than that, so it is a lower bound, and the exact answer on a uniform batch
+// — and looks at 64 spans per step, one per lane (one memory round trip, what the length lookup cost before).
+// Steps overlap by one span: lane 0 always starts at or before k, so the ballot is never empty.
+__device__ __forceinline__ Node find_node(const NodeSpan *__restrict__ spans, int B, long long k, long long per_b,
+                                          int lane) {
+    Node n = {0, 0, 0, 0, 0};
+    for (int b0 = (int)(k / per_b); b0 < B; b0 += kWave - 1) {
+        // one 16-byte load per lane (field by field hipcc fetched Ub1 in a second round trip after the ballot);
+        // lanes past the end see the total (> k) again
+        const u32x4 e = *reinterpret_cast<const u32x4 *>(spans + min(b0 + lane, B));
+        const long long e_first = (long long)(((unsigned long long)e.y << 32) | e.x);
+        const unsigned long long below = __ballot(e_first <= k);
+        if (below == ~0ull) continue;
+        const int src = __popcll(below) - 1;  // last span that starts at or before k: empty ones in front of it are skipped
+        const long long first = ((long long)__builtin_amdgcn_readlane((int)e.y, src) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)e.x, src);
+        n.b = b0 + src;
+        n.Tb = __builtin_amdgcn_readlane((int)e.z, src);
+        const int Ub1 = __builtin_amdgcn_readlane((int)e.w, src);
+        n.Ub = Ub1 - 1;
+        const int rem = (int)(k - first);
+        n.t = rem / Ub1;
+        n.u = rem - n.t * Ub1;
+        break;
+    }
+    return n;
+}
+
 template <typename DT, int NCH, int WPR, bool MIS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>), k1_waves(NCH, DT::EPC, MIS, WPR, kCvtUnpack<DT>))))
 void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
@@ -151,7 +232,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ act_lens,
                                                    const int *__restrict__ label_lens, Lattice L,
                                                    int maxT, int U1, int V, int blank,
-                                                   long long total_rows) {
+                                                   long long total_rows, int B) {
     constexpr int EPC = DT::EPC;
     constexpr int WPB = 4;          // waves per workgroup (host launches 256 threads)
     constexpr int RPB = WPB / WPR;  // nodes per workgroup
@@ -161,18 +242,20 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     const int rib = wave / WPR;
     const int seg = wave - rib * WPR;
     // !MIS: host guarantees V % EPC == 0, 16-byte aligned rows and V/EPC <= WPR*NCH*64 - 7
-    const long long ngroups = (total_rows + RPB - 1) / RPB;
+    // nodes inside the lattices (a scalar load: the surplus workgroups of a ragged batch leave at once)
+    const long long total = min(L.spans[B].first, total_rows);
+    const long long ngroups = (total + RPB - 1) / RPB;
+    const long long per_b = (long long)maxT * U1;
 
-    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {  // host launches ngroups blocks
-        const long long r = g * RPB + rib;
-        bool valid = r < total_rows;
-        const RowCoord c = decode_row(valid ? r : 0, maxT, U1);
-        const int Tb = act_lens[c.b];
-        const int Ub = label_lens[c.b];
-        valid = valid && lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub;  // padded node: never read
-        if (WPR == 1 && !valid) continue;
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {  // host launches one block per group of the FULL tensor
+        const long long k = g * RPB + rib;
+        const bool valid = k < total;  // padding is never visited
+        if (WPR == 1 && !valid) break;
+        const Node c = find_node(L.spans, B, valid ? k : 0, per_b, lane);
+        const int Ub = c.Ub;
+        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
 
-        const typename DT::elem *row = acts + (size_t)(valid ? r : 0) * (size_t)V;
+        const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
         const int shift = MIS ? (int)((addr & 15) / sizeof(typename DT::elem)) : 0;  // previous row's elements in chunk 0
         const u32x4 *row4 = MIS ? align_down16(row) : reinterpret_cast<const u32x4 *>(row);
@@ -441,7 +524,7 @@ template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
     const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
     const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-    int V, int blank, long long total_rows) {
+    int V, int blank, long long total_rows, int B) {
     constexpr int EPC = DT::EPC;
     constexpr int UNR = 8;
     __shared__ float red_m[4], red_s[4];
@@ -450,11 +533,12 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
     const int nchunks = V / EPC;  // host guarantees V % EPC == 0 and 16-byte aligned rows
     auto safe = [](float m) { return (m == -INFINITY || m == INFINITY) ? 0.0f : m; };  // as rnnt_k1_lse
 
-    for (long long r = blockIdx.x; r < total_rows; r += gridDim.x) {  // host launches one workgroup per node
-        const RowCoord c = decode_row(r, maxT, U1);
-        const int Tb = act_lens[c.b];
-        const int Ub = label_lens[c.b];
-        if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) continue;  // workgroup-uniform
+    const long long per_b = (long long)maxT * U1;
+    const long long total = min(L.spans[B].first, total_rows);
+    for (long long k = blockIdx.x; k < total; k += gridDim.x) {  // host launches one workgroup per node of the full tensor
+        const Node c = find_node(L.spans, B, k, per_b, lane);
+        const int Ub = c.Ub;
+        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
 
@@ -523,15 +607,16 @@ template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
     const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
     const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-    int V, int blank, long long total_rows) {
+    int V, int blank, long long total_rows, int B) {
     const int lane = threadIdx.x & (kWave - 1);
+    const long long per_b = (long long)maxT * U1;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    for (long long r = wave0; r < total_rows; r += nwaves) {
-        const RowCoord c = decode_row(r, maxT, U1);
-        const int Tb = act_lens[c.b];
-        const int Ub = label_lens[c.b];
-        if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) continue;
+    const long long total = min(L.spans[B].first, total_rows);
+    for (long long k = wave0; k < total; k += nwaves) {
+        const Node c = find_node(L.spans, B, k, per_b, lane);
+        const int Ub = c.Ub;
+        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         float m = -INFINITY;
         for (int v = lane; v < V; v += kWave) m = fmaxf(m, DT::to_float(row[v]));
@@ -1096,7 +1181,9 @@ inline size_t plane_floats(int maxT, int maxU, int B) {
     return (size_t)B * (ND + 1) * US + 2 * US;
 }
 
-// workspace = {m,l} (float2) | lp (float2) | alpha | beta | ll[B]; every plane starts 256-byte aligned
+// workspace = {m,l} (float2) | lp (float2) | alpha | beta | ll[B] | spans[B+1]; every part starts 256-byte aligned
+inline size_t ll_floats(int B) { return align_up((size_t)B, 64); }
+inline size_t spans_bytes(int B) { return align_up(((size_t)B + 1) * sizeof(NodeSpan), 256); }
 inline Lattice carve(void *ws, int maxT, int maxU, int B) {
     const size_t p = plane_floats(maxT, maxU, B);  // multiple of 64 floats = 256 bytes
     float *f = static_cast<float *>(ws);
@@ -1106,6 +1193,7 @@ inline Lattice carve(void *ws, int maxT, int maxU, int B) {
     L.alpha = f + 4 * p;
     L.beta = f + 5 * p;
     L.ll = f + 6 * p;
+    L.spans = reinterpret_cast<NodeSpan *>(f + 6 * p + ll_floats(B));
     L.ND = maxT + maxU - 1;
     L.US = row_stride(maxU);
     return L;
@@ -1245,11 +1333,13 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
         }
         return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
     }
+    // every other K1 walks the compacted node order (rnnt_node_spans above)
+    hipLaunchKernelGGL(rnnt_node_spans, dim3(1), dim3(kWave), 0, st, act_lens, label_lens, B, o.maxT, o.maxU, L.spans);
     const Tile t = pick_tile(acts, nullptr, V, o.dtype, 4);
     int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K1_GRID", 0);
     if (g > 0) grid = g;
-#define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
+#define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows, B
 #define K1_LAUNCH(N, W, M) hipLaunchKernelGGL((rnnt_k1_lse<DT, N, W, M>), dim3(grid), dim3(block), 0, st, K1_ARGS)
 // several waves per node only occur with 9+ chunks per lane (pick_tile): the others are not instantiated
 #define CASE(N)                                                                                        \
@@ -1398,7 +1488,7 @@ int rnnt_mi355_abi_version(void) { return kAbiVersion; }
 rnntStatus_t rnnt_get_workspace_size(int maxT, int maxU, int minibatch, size_t *size_bytes) {
     if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
     if (maxU > 512) return RNNT_STATUS_INVALID_VALUE;
-    *size_bytes = (6 * plane_floats(maxT, maxU, minibatch) + align_up((size_t)minibatch, 64)) * sizeof(float);
+    *size_bytes = (6 * plane_floats(maxT, maxU, minibatch) + ll_floats(minibatch)) * sizeof(float) + spans_bytes(minibatch);
     return RNNT_STATUS_SUCCESS;
 }
 

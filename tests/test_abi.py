@@ -54,10 +54,10 @@ def test_lattices_wider_than_512_columns_are_a_value_error_before_any_launch():
 
 
 def test_workspace_size():
-    # 6 fp32 planes of B*(ND+1)*US (+2 rows slack) + ll[B]; config 2: ND=440, US=64
+    # 6 fp32 planes of B*(ND+1)*US (+2 rows slack) + ll[B] + 16-byte node spans [B+1]; config 2: ND=440, US=64
     n = _lib.workspace_bytes(400, 41, 32)
     plane = 32 * 441 * 64 + 2 * 64
-    assert n == (6 * plane + 64) * 4
+    assert n == (6 * plane + 64) * 4 + 768
     assert n % 256 == 0
     lib = _lib.load()
     sz = ctypes.c_size_t(0)

@@ -64,7 +64,8 @@ def test_kat2_upstream_two_utterance_vector():
     assert np.abs(grads_mean - grads / 2).max() <= 1e-7
 
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(f).startswith("ref_"))   # ref_*: the joint / decoding fixtures (ref_fixtures.py)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -86,6 +87,39 @@ def test_small_ragged_vs_oracle(B, T, U, V, seed, reduction):
     acts, labels, al, ll = make_case(B, T, U, V, seed=seed, ragged=True, sigma=2.0)
     go = 0.5 if reduction != "none" else np.linspace(0.25, 1.5, B).astype(np.float32)
     check_against_oracle(acts, labels, al, ll, reduction, go)
+
+
+@pytest.mark.parametrize("V", [29, 520, 4232, 8200, 17412, 70001])   # small-row / one wave / two waves / streaming / generic K1
+@pytest.mark.parametrize("B", [63, 64, 65, 127, 130, 200])
+def test_many_ragged_utterances_compacted_node_order(B, V):
+    """K1 walks the nodes inside the lattices through per-utterance prefix offsets, 64 utterances per search step
+    (rnnt_node_spans / find_node): batches around and beyond one step, with utterances that have no nodes at all
+    (lengths that do not fit the tensor: NaN cost, zero gradient) at the start, in the middle and at the end."""
+    T, U = (6, 3) if V > 5000 else (11, 4)
+    acts, labels, al, ll = make_case(B, T, U, V, seed=B * 7 + V, ragged=True)
+    bad = [0, B // 2, 62 if B > 63 else 5, B - 1]
+    al_bad, ll_bad = al.copy(), ll.copy()
+    al_bad[bad[0]] = T + 1
+    ll_bad[bad[1]] = U + 1
+    al_bad[bad[2]] = 0
+    al_bad[bad[3]] = -3
+    import rnnt_amd
+
+    dev = torch.device("cuda:0")
+    a = torch.from_numpy(acts).to(dev).requires_grad_(True)
+    costs = rnnt_amd.RNNTLoss(reduction="none", check_lengths=False)(
+        a, torch.from_numpy(labels).to(dev), torch.from_numpy(al_bad).to(dev), torch.from_numpy(ll_bad).to(dev))
+    good = np.ones(B, bool)
+    good[bad] = False
+    go = torch.from_numpy(np.where(good, 1.0, 0.0).astype(np.float32)).to(dev)
+    costs.backward(go)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    got = costs.detach().cpu().numpy()
+    assert np.isnan(got[~good]).all()
+    np.testing.assert_allclose(got[good], c[good], rtol=LOSS_RTOL)
+    grads = a.grad.cpu().numpy()
+    assert np.abs(grads[good] - g[good]).max() <= GRAD_ATOL
+    assert not grads[~good].any()
 
 
 @pytest.mark.parametrize("V", [5, 6, 7, 29, 32, 33, 64, 100, 128, 250, 256, 257, 500, 512, 513, 1000, 1024, 4234,
