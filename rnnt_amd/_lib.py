@@ -176,6 +176,10 @@ class StageEvents:
     def ptr(self):
         return ctypes.cast(self.handles, ctypes.POINTER(ctypes.c_void_p))
 
+    def address(self) -> int:
+        """Address of the handle array, for the compiled binding (an ``int`` argument of ``torch.ops``)."""
+        return ctypes.addressof(self.handles)
+
     def elapsed_ms(self, i: int, j: int) -> float:
         ms = ctypes.c_float(0.0)
         check(load().rnnt_event_elapsed_ms(self.handles[i], self.handles[j], ctypes.byref(ms)),

@@ -11,6 +11,12 @@ The work is done by ``librnnt_mi355.so`` through its C ABI
 ``rnnt_backward`` in ``backward`` (K3, with ``grad_output`` and the ``1/B`` of
 'mean' fused in).  PyTorch only provides device memory and the current stream.
 There is no CPU path and no fallback: CPU tensors raise.
+
+Two bindings drive that C ABI.  The default, ``"torch"``, is the compiled extension
+``librnnt_amd_torch.so`` (``rnnt_amd/csrc/torch_binding.cpp``): one ``torch.ops.rnnt_amd.rnnt_loss`` call
+per step, backward recorded as a C++ autograd node.  ``"ctypes"`` is the same sequence written in Python
+(``_RNNTLossFunction`` below), kept as the worked example of ``INTEGRATION.md`` §2 and for A/B runs
+(``tools/bench_host_overhead.py``); select it with ``set_binding("ctypes")`` or ``binding="ctypes"``.
 """
 from __future__ import annotations
 
@@ -19,7 +25,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, _torch_binding
 
 _DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _REDUCTIONS = {"none": _lib.REDUCTION_NONE, "mean": _lib.REDUCTION_MEAN, "sum": _lib.REDUCTION_SUM}
@@ -30,6 +36,21 @@ MAX_LATTICE_COLUMNS = 512  # maxU = U + 1 the library accepts (include/rnnt_mi35
 # the library on the launch stream.  None in normal use.
 _profile_fwd: Optional[_lib.StageEvents] = None
 _profile_bwd: Optional[_lib.StageEvents] = None
+
+
+_binding = "torch"
+
+
+def set_binding(name: str) -> None:
+    """Process-wide default binding of :func:`rnnt_loss`: ``"torch"`` (compiled extension) or ``"ctypes"``."""
+    global _binding
+    if name not in ("torch", "ctypes"):
+        raise ValueError("binding must be 'torch' or 'ctypes'")
+    _binding = name
+
+
+def get_binding() -> str:
+    return _binding
 
 
 def set_stage_events(fwd: Optional[_lib.StageEvents], bwd: Optional[_lib.StageEvents]) -> None:
@@ -186,7 +207,16 @@ def reduce_costs(costs: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
     return out
 
 
-def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", check_lengths=True):
+def _apply(acts, labels, act_lens, label_lens, blank, reduction, binding):
+    if binding == "ctypes":
+        return _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+    return _torch_binding.load().rnnt_loss(
+        acts, labels, act_lens, label_lens, int(blank), _REDUCTIONS[reduction],
+        _profile_fwd.address() if _profile_fwd is not None else 0,
+        _profile_bwd.address() if _profile_bwd is not None else 0)
+
+
+def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", check_lengths=True, binding=None):
     """RNN Transducer loss (functional form of :class:`RNNTLoss`).
 
     Args:
@@ -196,7 +226,11 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", che
         label_lens: ``[B]`` int32 labels per utterance.
         blank: blank label index (default 0, as the reference uses).
         reduction: ``'mean'`` (sum / B, shape ``[1]``), ``'sum'`` (``[1]``) or ``'none'`` (``[B]``).
+        binding: ``"torch"`` | ``"ctypes"`` | None (the process default, see :func:`set_binding`).
     """
+    binding = _binding if binding is None else binding
+    if binding not in ("torch", "ctypes"):
+        raise ValueError("binding must be 'torch' or 'ctypes'")
     if reduction not in _REDUCTIONS:
         raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
     certify_inputs(acts, labels, act_lens, label_lens, check_lengths=False)
@@ -210,10 +244,10 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", che
     if not (0 <= int(blank) < acts.shape[3]):
         raise ValueError("blank label out of range")
     if not check_lengths:
-        return _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+        return _apply(acts, labels, act_lens, label_lens, blank, reduction, binding)
     with torch.cuda.device(acts.device):
         pending = _start_length_fetch(acts, act_lens, label_lens)
-        loss = _RNNTLossFunction.apply(acts, labels, act_lens, label_lens, blank, reduction)
+        loss = _apply(acts, labels, act_lens, label_lens, blank, reduction, binding)
         _validate_lengths(*pending)  # raises ValueError like upstream; the launched kernels were harmless
     return loss
 
@@ -224,23 +258,27 @@ class RNNTLoss(torch.nn.Module):
     Parameters:
         blank (int, default 0): blank label.
         reduction (str, default 'mean'): 'none' | 'mean' | 'sum'; 'mean' divides by the batch size.
+        binding (str or None): ``"torch"`` (compiled extension, the default) or ``"ctypes"``.
         check_lengths (bool, default True): verify on the host that the length tensors fit the
             logits tensor (one tiny device-to-host copy, as upstream).  The kernels guard
             themselves either way: an utterance with out-of-range lengths or labels yields a NaN
             cost and zero gradient instead of an out-of-bounds access.
     """
 
-    def __init__(self, blank: int = 0, reduction: str = "mean", check_lengths: bool = True):
+    def __init__(self, blank: int = 0, reduction: str = "mean", check_lengths: bool = True, binding=None):
         super().__init__()
         if reduction not in _REDUCTIONS:
             raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
+        if binding not in (None, "torch", "ctypes"):
+            raise ValueError("binding must be 'torch' or 'ctypes'")
         self.blank = blank
         self.reduction = reduction
         self.check_lengths = check_lengths
+        self.binding = binding  # None: the process default (rnnt_amd.loss.set_binding)
 
     def forward(self, acts, labels, act_lens, label_lens):
         return rnnt_loss(acts, labels, act_lens, label_lens, self.blank, self.reduction,
-                         self.check_lengths)
+                         self.check_lengths, self.binding)
 
     def extra_repr(self) -> str:
         return f"blank={self.blank}, reduction='{self.reduction}'"

@@ -167,3 +167,20 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "rnnt_oracle" not in text, fn
+
+
+def test_compiled_torch_binding_loads_without_a_gpu():
+    """librnnt_amd_torch.so registers torch.ops.rnnt_amd.* on import; nothing is computed here."""
+    import torch
+
+    from rnnt_amd import _torch_binding
+
+    ops = _torch_binding.load()
+    assert ops.abi_version() == _lib.ABI_VERSION
+    for name in ("rnnt_loss", "rnnt_forward", "rnnt_backward"):
+        assert hasattr(ops, name)
+    a = torch.zeros(1, 2, 3, 5)
+    lab = torch.ones(1, 2, dtype=torch.int32)
+    one = torch.ones(1, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.rnnt_loss(a, lab, one, one, 0, 1)
