@@ -13,7 +13,8 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (K3, the fus
 pass): algorithmic bytes per launch (read N_valid + write N_full elements) over its mean
 duration measured with hipEvents that the library records on the launch stream.  `cpu_baseline`
 is the CPU oracle (oracle/rnnt_oracle.c, a restatement of warp-transducer's CPU semantics — NOT
-warp-transducer itself) timed on this host on a bounded sample of the same workload.
+warp-transducer itself) timed on this host on the first utterances of the very batch the GPU ran,
+as one native call (`value`) and in upstream's shape (`upstream_shaped`: torch.log_softmax -> C -> autograd).
 """
 from __future__ import annotations
 
@@ -71,20 +72,26 @@ def make_device_batch(w, dev, first_utt, seed=1234):
             torch.from_numpy(label_lens).to(dev), act_lens, label_lens)
 
 
-def cpu_baseline(w, sample_B, reps):
-    """CPU oracle (restatement of warp-transducer's CPU path) on a bounded sample, host cores."""
+def cpu_baseline(w, acts_dev, labels_dev, al, ll, sample_B, reps):
+    """The loss on this host's cores, on the FIRST sample_B utterances of the very batch the GPU was timed on
+    (copied back from the device: same per-utterance-seeded logits, labels and lengths), two ways:
+
+    * ``value``: the all-C port (oracle/rnnt_oracle.c: log-softmax, alpha/beta, gradient and log-softmax backward
+      in one OpenMP native call, one utterance per thread);
+    * ``upstream_shaped``: the way upstream's CPU path is shaped: ``torch.log_softmax`` in
+      Python -> native alpha/beta + sparse gradient -> autograd back through the log-softmax.
+    Neither is warp-transducer itself (its sources are not available here): kind = "port".
+    """
     import oracle  # test infrastructure: used here only as the reported CPU baseline
 
     oracle.build()
+    per_utt = w["T"] * (w["U"] + 1) * w["V"]
     # bounded sample: at most ~2.5e9 logits (10 GB of fp32 logits + as much for the gradient) on the host
-    sample_B = max(1, min(sample_B, int(2.5e9 // (w["T"] * (w["U"] + 1) * w["V"]))))
-    B, T, U, V = sample_B, w["T"], w["U"], w["V"]
-    g = torch.Generator().manual_seed(1234)
-    acts = torch.empty((B, T, U + 1, V), dtype=torch.float32).normal_(0, 1, generator=g).numpy()
-    rng = np.random.default_rng(4321)
-    labels = rng.integers(1, V, size=(B, U)).astype(np.int32)
-    al = np.full(B, T, np.int32)
-    ll = np.full(B, U, np.int32)
+    B = max(1, min(sample_B, w["B"], int(2.5e9 // per_utt)))
+    T, U, V = w["T"], w["U"], w["V"]
+    acts = acts_dev[:B].detach().float().cpu().numpy()
+    labels = labels_dev[:B].cpu().numpy()
+    al, ll = np.ascontiguousarray(al[:B]), np.ascontiguousarray(ll[:B])
     threads = oracle.max_threads()
     oracle.rnnt_loss_c(acts[:1], labels[:1], al[:1], ll[:1])  # warm-up (page in, thread pool)
     ts = []
@@ -95,12 +102,28 @@ def cpu_baseline(w, sample_B, reps):
         ts.append(time.perf_counter() - t0)
         del gr
     t = float(np.median(ts))
+    # the upstream-shaped path holds the logits, the log-probs and two gradients at once: half the sample
+    Bu = max(1, min(B, int(1.25e9 // per_utt)))
+    tu = []
+    for _ in range(max(2, reps // 2)):
+        t0 = time.perf_counter()
+        lu, gu = oracle.rnnt_loss_upstream_shaped(acts[:Bu], labels[:Bu], al[:Bu], ll[:Bu], reduction="mean",
+                                                  grad_output=0.5)
+        tu.append(time.perf_counter() - t0)
+        del gu
+    tu = float(np.median(tu))
+    lens = "uniform lengths" if not w["ragged"] else "the batch's own ragged lengths"
     return {
         "value": B / t, "unit": "utt/s", "cores": int(min(threads, B)), "kind": "port",
-        "sample": f"CPU restatement of warp-transducer semantics (oracle/rnnt_oracle.c, OpenMP, one "
-                  f"utterance per thread), fwd+bwd on B={B} utterances of T={T} U={U} V={V} fp32, "
-                  f"median of {reps} runs, {t * 1e3:.0f} ms per run; omp_max_threads={threads}, "
-                  f"os.cpu_count={os.cpu_count()}",
+        "sample": f"value = ALL-C port (oracle/rnnt_oracle.c, OpenMP, one utterance per thread; a restatement of "
+                  f"warp-transducer's CPU semantics, not warp-transducer itself), fwd+bwd on the first B={B} "
+                  f"utterances of the GPU run's own batch (per-utterance seeds, copied back from the device), "
+                  f"T={T} U={U} V={V} fp32, {lens}, median of {reps} runs, {t * 1e3:.0f} ms per run; "
+                  f"upstream_shaped = torch.log_softmax -> C alpha/beta + sparse grad -> autograd on the first "
+                  f"B={Bu} of the same utterances, {tu * 1e3:.0f} ms per run; omp_max_threads={threads}, "
+                  f"torch threads={torch.get_num_threads()}, os.cpu_count={os.cpu_count()}",
+        "upstream_shaped": {"value": Bu / tu, "unit": "utt/s", "cores": int(torch.get_num_threads()),
+                            "kind": "port", "loss": float(lu[0])},
     }
 
 
@@ -260,6 +283,7 @@ def main():
             "unit": "GB/s",
             "frac": round(k3_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": None,
+            "traffic_source": None,
             "algorithmic_bytes_per_launch": k3_bytes,
             "avg_launch_ms": round(k3, 4),
         },
@@ -273,17 +297,24 @@ def main():
         },
         "loss": loss_val,
     }
+    # HBM bytes per K3 launch from the PMC counters cannot be collected inside this process: they come from the
+    # committed rocprofv3 passes over this same command (tools/profile.sh), and only for the workload they ran.
     traffic_file = os.path.join(ROOT, "profiles", "k3_traffic.json")
-    if os.path.exists(traffic_file) and args.workload == "config2":
+    if os.path.exists(traffic_file) and args.workload == "config2" and world == 1:
         try:
             with open(traffic_file) as f:
-                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = (
+                f"profiles/k3_traffic.json ({tj.get('collected', 'round 1')}: rocprofv3 --pmc FETCH_SIZE / "
+                f"WRITE_SIZE passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, FETCH_SIZE "
+                f"doubled as MI355X_MICROARCH.md prescribes; NOT measured in this run)")
         except Exception:
             pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # free the device tensors' host shadows first; the CPU sample needs a few GB of RAM
-        out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample_b, args.cpu_reps)
+        out["cpu_baseline"] = cpu_baseline(w, acts, labels, al, ll, args.cpu_sample_b, args.cpu_reps)
     elif rank == 0:
         out["cpu_baseline"] = None
     sys.stdout.flush()

@@ -63,6 +63,13 @@ def _load():
             fn.argtypes = [p, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                            ctypes.c_int, p, p, p, ctypes.c_int]
             fn.restype = ctypes.c_int
+        for name, real in (("rnnt_oracle_logprobs_f32", ctypes.c_float), ("rnnt_oracle_logprobs_f64", ctypes.c_double)):
+            fn = getattr(lib, name)
+            p = ctypes.POINTER(real)
+            ip = ctypes.POINTER(ctypes.c_int)
+            fn.argtypes = [p, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                           ctypes.c_int, p, p, ctypes.c_int]
+            fn.restype = ctypes.c_int
         lib.rnnt_oracle_max_threads.restype = ctypes.c_int
         _lib = lib
     return _lib
@@ -107,6 +114,41 @@ def rnnt_loss_c(acts, labels, act_lens, label_lens, blank=0, want_grads=True, dt
     if rc != 0:
         raise ValueError("rnnt_oracle: invalid arguments (lengths/labels out of range?)")
     return costs, grads, llb
+
+
+def rnnt_loss_upstream_shaped(acts, labels, act_lens, label_lens, blank=0, reduction="mean", grad_output=1.0,
+                              num_threads=0):
+    """The loss the way upstream's CPU path is SHAPED: ``torch.log_softmax`` in Python,
+    the native call for alpha/beta and the sparse gradient w.r.t. the log-probs, autograd back through the
+    log_softmax, the reduction in Python.  Returns ``(loss ndarray, grads ndarray)``; same numbers as
+    :func:`rnnt_loss_c` + :func:`reduce_like_upstream` up to rounding (tests/test_oracle.py)."""
+    import torch
+
+    lib = _load()
+    x = torch.from_numpy(np.ascontiguousarray(acts)).requires_grad_(True)
+    dtype = np.dtype(np.float64 if x.dtype is torch.float64 else np.float32)
+    x32 = x if x.dtype in (torch.float32, torch.float64) else x.float()
+    lp = torch.nn.functional.log_softmax(x32, dim=-1)
+    lp_np = lp.detach().numpy()
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    act_lens = np.ascontiguousarray(act_lens, dtype=np.int32)
+    label_lens = np.ascontiguousarray(label_lens, dtype=np.int32)
+    B, T, U1, V = lp_np.shape
+    costs = np.empty(B, dtype=dtype)
+    g_lp = np.empty_like(lp_np)
+    real = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    fn = lib.rnnt_oracle_logprobs_f32 if dtype == np.float32 else lib.rnnt_oracle_logprobs_f64
+    P, IP = ctypes.POINTER(real), ctypes.POINTER(ctypes.c_int)
+    rc = fn(lp_np.ctypes.data_as(P), labels.ctypes.data_as(IP), act_lens.ctypes.data_as(IP),
+            label_lens.ctypes.data_as(IP), B, T, U1, V, int(blank), costs.ctypes.data_as(P), g_lp.ctypes.data_as(P),
+            int(num_threads))
+    if rc != 0:
+        raise ValueError("rnnt_oracle_logprobs: invalid arguments (lengths/labels out of range?)")
+    scale = {"mean": 1.0 / B, "sum": 1.0, "none": 1.0}[reduction]
+    go = np.broadcast_to(np.asarray(grad_output, dtype=dtype), (B,)).reshape(B, 1, 1, 1) * scale
+    lp.backward(torch.from_numpy(g_lp * go))
+    loss = costs if reduction == "none" else np.array([costs.sum(dtype=dtype) * scale], dtype=dtype)
+    return loss, x.grad.numpy()
 
 
 def reduce_like_upstream(costs, grads, reduction="mean", grad_output=1.0):

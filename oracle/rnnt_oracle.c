@@ -118,3 +118,45 @@ int rnnt_oracle_max_threads(void) {
 
 DEFINE_BATCH(float, _f32)
 DEFINE_BATCH(double, _f64)
+
+/*
+ * The native half of the upstream-shaped CPU path (bench.py's second CPU baseline): log_probs
+ * [B, maxT, maxU, V] as torch.log_softmax left them; costs [B]; grads_lp [B, maxT, maxU, V] or NULL <- the
+ * sparse d costs[b] / d log_probs[b] (zeros elsewhere).  Same OpenMP loop over the minibatch.
+ */
+#define DEFINE_BATCH_LOGPROBS(REAL, SUFFIX)                                                          \
+    int rnnt_oracle_logprobs##SUFFIX(const REAL *lp, const int *labels, const int *act_lens,         \
+                                     const int *label_lens, int B, int maxT, int maxU, int V,        \
+                                     int blank, REAL *costs, REAL *grads_lp, int num_threads) {      \
+        if (!lp || !labels || !act_lens || !label_lens || !costs) return -1;                         \
+        if (B <= 0 || maxT <= 0 || maxU <= 0 || V <= 0 || blank < 0 || blank >= V) return -1;        \
+        for (int b = 0; b < B; ++b) {                                                                \
+            if (act_lens[b] < 1 || act_lens[b] > maxT) return -1;                                    \
+            if (label_lens[b] < 0 || label_lens[b] + 1 > maxU) return -1;                            \
+            for (int u = 0; u < label_lens[b]; ++u) {                                                \
+                const int y = labels[(size_t)b * (size_t)(maxU - 1) + u];                            \
+                if (y < 0 || y >= V) return -1;                                                      \
+            }                                                                                        \
+        }                                                                                            \
+        const size_t per_utt = (size_t)maxT * (size_t)maxU * (size_t)V;                              \
+        if (grads_lp) memset(grads_lp, 0, per_utt * (size_t)B * sizeof(REAL));                       \
+        int fail = 0;                                                                                \
+        if (num_threads <= 0) num_threads = rnnt_oracle_max_threads();                               \
+        _Pragma("omp parallel for schedule(dynamic, 1) num_threads(num_threads)")                    \
+        for (int b = 0; b < B; ++b) {                                                                \
+            const int T = act_lens[b], U = label_lens[b] + 1;                                        \
+            REAL *ab = (REAL *)malloc((size_t)2 * T * U * sizeof(REAL));                             \
+            if (!ab) {                                                                               \
+                fail = 1;                                                                            \
+            } else {                                                                                 \
+                costs[b] = -rnnt_one_utt_logprobs##SUFFIX(                                           \
+                    lp + per_utt * (size_t)b, labels + (size_t)b * (size_t)(maxU - 1), T, U, maxU,   \
+                    V, blank, ab, ab + (size_t)T * U, grads_lp ? grads_lp + per_utt * (size_t)b : NULL); \
+            }                                                                                        \
+            free(ab);                                                                                \
+        }                                                                                            \
+        return fail ? -1 : 0;                                                                        \
+    }
+
+DEFINE_BATCH_LOGPROBS(float, _f32)
+DEFINE_BATCH_LOGPROBS(double, _f64)

@@ -28,33 +28,13 @@ static inline REAL FN(log_sum_exp)(REAL a, REAL b) {
 }
 
 /*
- * One utterance.  lp is a scratch buffer of T*U*V log-probs (the tensor the
- * upstream CPU path materialises with torch.log_softmax before the native
- * call); alphas/betas are T*U scratch.  grads may be NULL (forward only).
- * Returns the forward log-likelihood.
+ * A4: alpha / beta over one utterance's T x U lattice of materialised log-probs; row (t,u) starts at
+ * lp + t*t_stride + u*V.  Returns ll = alpha(T-1,U-1) + lp_blank(T-1,U-1); *ll_backward_out = beta(0,0).
  */
-static REAL FN(rnnt_one_utt)(const REAL *acts, const int *labels, int T, int U, int maxU, int V,
-                             int blank, REAL *lp, REAL *alphas, REAL *betas, REAL *grads,
-                             REAL *ll_backward_out) {
-    const size_t t_stride = (size_t)maxU * (size_t)V;
-#define ROW(t, u) (acts + (size_t)(t) * t_stride + (size_t)(u) * (size_t)V)
-#define LP(t, u) (lp + ((size_t)(t) * (size_t)U + (size_t)(u)) * (size_t)V)
+static REAL FN(rnnt_lattice)(const REAL *lp, size_t t_stride, const int *labels, int T, int U, int V, int blank,
+                             REAL *alphas, REAL *betas, REAL *ll_backward_out) {
+#define LP(t, u) (lp + (size_t)(t) * t_stride + (size_t)(u) * (size_t)V)
 #define IDX(t, u) ((size_t)(t) * (size_t)U + (size_t)(u))
-
-    /* A3: log_softmax over V, computed as torch does it: (x - max) - log(sum exp(x - max)) */
-    for (int t = 0; t < T; ++t) {
-        for (int u = 0; u < U; ++u) {
-            const REAL *x = ROW(t, u);
-            REAL *o = LP(t, u);
-            REAL mx = x[0];
-            for (int v = 1; v < V; ++v) mx = x[v] > mx ? x[v] : mx;
-            REAL s = 0;
-            for (int v = 0; v < V; ++v) s += EXP(x[v] - mx);
-            const REAL ls = LOG(s);
-            for (int v = 0; v < V; ++v) o[v] = (x[v] - mx) - ls;
-        }
-    }
-
     /* A4: alphas */
     alphas[0] = 0;
     for (int t = 0; t < T; ++t) {
@@ -84,6 +64,42 @@ static REAL FN(rnnt_one_utt)(const REAL *acts, const int *labels, int T, int U, 
         }
     }
     if (ll_backward_out) *ll_backward_out = betas[0];
+    return ll;
+#undef LP
+#undef IDX
+}
+
+/*
+ * One utterance.  lp is a scratch buffer of T*U*V log-probs (the tensor the
+ * upstream CPU path materialises with torch.log_softmax before the native
+ * call); alphas/betas are T*U scratch.  grads may be NULL (forward only).
+ * Returns the forward log-likelihood.
+ */
+static REAL FN(rnnt_one_utt)(const REAL *acts, const int *labels, int T, int U, int maxU, int V,
+                             int blank, REAL *lp, REAL *alphas, REAL *betas, REAL *grads,
+                             REAL *ll_backward_out) {
+    const size_t t_stride = (size_t)maxU * (size_t)V;
+#define ROW(t, u) (acts + (size_t)(t) * t_stride + (size_t)(u) * (size_t)V)
+#define LP(t, u) (lp + ((size_t)(t) * (size_t)U + (size_t)(u)) * (size_t)V)
+#define IDX(t, u) ((size_t)(t) * (size_t)U + (size_t)(u))
+
+    /* A3: log_softmax over V, computed as torch does it: (x - max) - log(sum exp(x - max)) */
+    for (int t = 0; t < T; ++t) {
+        for (int u = 0; u < U; ++u) {
+            const REAL *x = ROW(t, u);
+            REAL *o = LP(t, u);
+            REAL mx = x[0];
+            for (int v = 1; v < V; ++v) mx = x[v] > mx ? x[v] : mx;
+            REAL s = 0;
+            for (int v = 0; v < V; ++v) s += EXP(x[v] - mx);
+            const REAL ls = LOG(s);
+            for (int v = 0; v < V; ++v) o[v] = (x[v] - mx) - ls;
+        }
+    }
+
+    /* A4: alphas, betas (shared with the log-probs entry point below) */
+    const REAL ll = FN(rnnt_lattice)(lp, (size_t)U * (size_t)V, labels, T, U, V, blank, alphas, betas,
+                                     ll_backward_out);
 
     if (grads) {
         /* A5: sparse d(-ll)/d(lp) (two entries per node), then densified through
@@ -108,6 +124,37 @@ static REAL FN(rnnt_one_utt)(const REAL *acts, const int *labels, int T, int U, 
     }
     return ll;
 #undef ROW
+#undef LP
+#undef IDX
+}
+
+/*
+ * One utterance of the upstream-SHAPED CPU path: the caller (upstream's Python glue) has already run
+ * torch.log_softmax; the native call walks the lattice on those log-probs and leaves the SPARSE gradient
+ * d(-ll)/d(lp) — two entries per node, the rest of the (pre-zeroed) tensor untouched — for autograd to carry
+ * back through the log_softmax.  lp and grads_lp are [maxT, maxU, V] slices (row stride maxU*V).
+ */
+static REAL FN(rnnt_one_utt_logprobs)(const REAL *lp, const int *labels, int T, int U, int maxU, int V, int blank,
+                                      REAL *alphas, REAL *betas, REAL *grads_lp) {
+    const size_t t_stride = (size_t)maxU * (size_t)V;
+#define LP(t, u) (lp + (size_t)(t) * t_stride + (size_t)(u) * (size_t)V)
+#define IDX(t, u) ((size_t)(t) * (size_t)U + (size_t)(u))
+    const REAL ll = FN(rnnt_lattice)(lp, t_stride, labels, T, U, V, blank, alphas, betas, NULL);
+    if (grads_lp) {
+        for (int t = 0; t < T; ++t) {
+            for (int u = 0; u < U; ++u) {
+                const REAL *o = LP(t, u);
+                REAL *g = grads_lp + (size_t)t * t_stride + (size_t)u * (size_t)V;
+                REAL g_blank = 0, g_label = 0;
+                if (t < T - 1) g_blank = -EXP(alphas[IDX(t, u)] + betas[IDX(t + 1, u)] + o[blank] - ll);
+                if (t == T - 1 && u == U - 1) g_blank = -EXP(alphas[IDX(t, u)] + o[blank] - ll);
+                if (u < U - 1) g_label = -EXP(alphas[IDX(t, u)] + betas[IDX(t, u + 1)] + o[labels[u]] - ll);
+                g[blank] += g_blank;
+                if (u < U - 1) g[labels[u]] += g_label;
+            }
+        }
+    }
+    return ll;
 #undef LP
 #undef IDX
 }

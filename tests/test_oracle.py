@@ -193,3 +193,29 @@ def test_oracle_under_sanitizers():
     out = subprocess.run([os.path.join(here, "selftest_asan")], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "oracle selftest ok" in out.stdout
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_upstream_shaped_path_equals_the_all_c_one(reduction, dtype):
+    """torch.log_softmax -> native alpha/beta + sparse gradient -> autograd (how upstream's CPU path is shaped,
+    bench.py's second CPU baseline) against the all-C statement: same costs and gradients up to rounding, on the
+    two known answers and a ragged batch with padding."""
+    k1 = oracle.rnnt_loss_upstream_shaped(KAT1["acts"].astype(dtype), KAT1["labels"], KAT1["act_lens"],
+                                          KAT1["label_lens"], reduction="sum")
+    np.testing.assert_allclose(k1[0][0], KAT1["cost"], rtol=1e-6)
+    assert np.abs(k1[1] - KAT1["grads"]).max() <= 1e-6
+    acts, labels, al, ll = make_case(5, 13, 6, 31, seed=11, ragged=True, sigma=2.0)
+    acts = acts.astype(dtype)
+    go = 0.5 if reduction != "none" else np.linspace(0.25, 1.5, 5).astype(dtype)
+    loss, grads = oracle.rnnt_loss_upstream_shaped(acts, labels, al, ll, reduction=reduction, grad_output=go)
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll, dtype=dtype)
+    ref_loss, ref_g = oracle.reduce_like_upstream(c, g, reduction, go)
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(loss, ref_loss, rtol=tol)
+    # fp32: torch's log_softmax and the C one round differently, and exp(alpha + beta - ll) carries that
+    assert np.abs(grads - ref_g).max() <= (1e-5 if dtype == np.float32 else 1e-13)
+    pad = np.ones(acts.shape[:3], bool)
+    for b in range(5):
+        pad[b, :al[b], :ll[b] + 1] = False
+    assert not grads[pad].any()

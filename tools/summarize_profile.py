@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 OUT = os.path.join(ROOT, "profiles")
-KERNELS = ("rnnt_k1_lse", "rnnt_k2_lattice", "rnnt_reduce_costs", "rnnt_k3_grad")
+KERNELS = ("rnnt_node_spans", "rnnt_k1_lse", "rnnt_k2_lattice", "rnnt_reduce_costs", "rnnt_k3_grad")
 # config 2 (bench.py default): B32 T400 U40 V4232 fp32, uniform lengths
 N = 32 * 400 * 41 * 4232
 ALGO = {"rnnt_k3_grad": 2 * N * 4, "rnnt_k1_lse": N * 4}
@@ -74,6 +74,7 @@ def main():
         out[key] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                     "algorithmic_bytes": ALGO[k], "ratio": (rd + wr) / ALGO[k]}
     out["hbm_bytes_per_launch"] = out["k3"]["hbm_bytes_per_launch"]
+    out["collected"] = f"round {int(TAG[1:])}" if TAG[1:].isdigit() else TAG
     out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `python3 bench.py "
                      "--steps 3 --warmup 1 --no-cpu-baseline` (tools/profile.sh), summarised by "
                      "tools/summarize_profile.py; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md")
