@@ -32,7 +32,7 @@ def short(name):
 
 
 def kernel_stats():
-    (path,) = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
+    path = max(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # newest run
     rows = list(csv.reader(open(path)))
     head, body = rows[0], rows[1:]
     ours = [r for r in body if short(r[0])]
@@ -47,7 +47,7 @@ def kernel_stats():
 def counter(which, name):
     per = {k: [] for k in KERNELS}
     lines = []
-    for path in glob.glob(os.path.join(SRC, which, "*", "*_counter_collection.csv")):
+    for path in [max(glob.glob(os.path.join(SRC, which, "*", "*_counter_collection.csv")), key=os.path.getmtime)]:
         for r in csv.DictReader(open(path)):
             k = short(r["Kernel_Name"])
             if k and r["Counter_Name"] == name:
