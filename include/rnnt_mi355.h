@@ -22,6 +22,9 @@
  *            maxU = max label length + 1   (model.py:115 produces this layout)
  *     labels [B, maxU-1] int32, zero padded, WITHOUT the BOS (model.py:116)
  *     act_lens, label_lens [B] int32
+ *   - maxU <= RNNT_MAX_LATTICE_COLUMNS (4095 labels per utterance); a wider lattice is INVALID_VALUE.  Up to 512
+ *     columns the lattice pass keeps one column per lane; beyond that a slower kernel takes over (~1-2 us per
+ *     anti-diagonal).  Upstream has no such limit; the reference's data never exceeds 150 labels.
  *   - degenerate numerics give NaN/Inf in the costs, not an error status
  *     (/root/reference/bin/train.py:36-41 consumes NaN/Inf losses).
  */
@@ -33,6 +36,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define RNNT_MAX_LATTICE_COLUMNS 4096
 
 typedef enum {
     RNNT_STATUS_SUCCESS = 0,

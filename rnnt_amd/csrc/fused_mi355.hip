@@ -528,7 +528,7 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
     if (alphabet_size < 64) return RNNT_STATUS_INVALID_VALUE;  // a tile is 64 vocabulary entries wide
-    if (alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.maxU > 512)
+    if (alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.maxU > RNNT_MAX_LATTICE_COLUMNS)
         return RNNT_STATUS_INVALID_VALUE;
     if (options.blank_label < 0 || options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     if (options.dtype != RNNT_DTYPE_BF16 && options.dtype != RNNT_DTYPE_F16) return RNNT_STATUS_INVALID_VALUE;

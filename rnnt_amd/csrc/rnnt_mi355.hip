@@ -787,6 +787,74 @@ __global__ __launch_bounds__(2 * NW * kWave) void rnnt_k2_lattice(Lattice L, flo
     }
 }
 
+// Lattices wider than 512 columns (more than 511 labels; upstream has no such limit, the reference's data
+// never comes near it): one workgroup of 1024 threads per utterance, threads [0,512) walk alpha up the
+// anti-diagonals and [512,1024) walk beta down, each thread taking columns j, j+512, ...  The previous
+// diagonal lives in LDS (two ping-pong rows of US floats per direction), one barrier per diagonal; same
+// operands in the same order as rnnt_k2_lattice, so a lattice that fits both gives the same bits.
+// Latency-bound like the fast kernel, without its register prefetch: ~1-2 us per diagonal.
+constexpr int kMaxLatticeColumns = RNNT_MAX_LATTICE_COLUMNS;  // 16 bytes of LDS per column: 64 KiB
+static_assert(kMaxLatticeColumns % 64 == 0 && kMaxLatticeColumns * 16 <= 64 * 1024, "LDS of rnnt_k2_lattice_wide");
+__global__ __launch_bounds__(1024) void rnnt_k2_lattice_wide(Lattice L, float *__restrict__ costs,
+                                                             const int *__restrict__ act_lens,
+                                                             const int *__restrict__ label_lens, int maxT,
+                                                             int U1) {
+    extern __shared__ float diag[];  // [direction][step parity][US]
+    const int US = L.US;
+    const int b = blockIdx.x;
+    const int T = act_lens[b];
+    const int U = label_lens[b];
+    if (!lens_ok(T, U, maxT, U1)) {  // block-uniform exit, before any barrier
+        if (threadIdx.x == 0) {
+            L.ll[b] = __builtin_nanf("");
+            costs[b] = __builtin_nanf("");
+        }
+        return;
+    }
+    const int dir = threadIdx.x >> 9;
+    const int j = threadIdx.x & 511;
+    const int nd = T + U;  // diagonals 0 .. nd-1
+    const size_t base = (size_t)b * (L.ND + 1) * US;
+    float *mine = diag + (size_t)dir * 2 * US;
+    const float NEG = -INFINITY;
+    for (int s = 0; s < nd; ++s) {
+        const int d = dir == 0 ? s : nd - 1 - s;
+        float *cur = mine + (size_t)(s & 1) * US;
+        const float *prv = mine + (size_t)((s + 1) & 1) * US;
+        const int u_lo = max(0, d - (T - 1)), u_hi = min(U, d);  // nodes (d-u, u) of this diagonal
+        for (int u = u_lo + j; u <= u_hi; u += 512) {
+            const int t = d - u;
+            const size_t o = base + (size_t)d * US + u;
+            if (dir == 0) {
+                // alpha(t,u) = logaddexp(alpha(t,u-1) + lp_label(t,u-1), alpha(t-1,u) + lp_blank(t-1,u)); both
+                // source nodes sit on diagonal d-1, columns u-1 and u
+                float left = NEG, up = (d == 0) ? 0.0f : NEG;  // a virtual 0 enters (0,0)
+                if (u > 0) left = prv[u - 1] + L.lp[o - US - 1].y;
+                if (t > 0) up = prv[u] + L.lp[o - US].x;
+                const float a = log_add_exp(left, up);
+                cur[u] = a;
+                L.alpha[o] = a;
+                if (d == nd - 1) {  // node (T-1, U)
+                    const float lik = a + L.lp[o].x;
+                    L.ll[b] = lik;
+                    costs[b] = -lik;
+                }
+            } else {
+                // beta(t,u) = logaddexp(beta(t,u+1) + lp_label(t,u), beta(t+1,u) + lp_blank(t,u)); both source
+                // nodes sit on diagonal d+1, columns u+1 and u
+                const float2 lp = L.lp[o];
+                float right = NEG, down = (s == 0) ? 0.0f : NEG;  // a virtual 0 leaves (T-1,U) through blank
+                if (u < U) right = prv[u + 1];
+                if (t < T - 1) down = prv[u];
+                const float v = log_add_exp(right + lp.y, down + lp.x);
+                cur[u] = v;
+                L.beta[o] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // costs -> loss_out, fixed summation order (bitwise reproducible, identical on every rank)
 __global__ void rnnt_reduce_costs_kernel(const float *__restrict__ costs, float *__restrict__ loss_out,
                                          int B, int reduction) {
@@ -1205,7 +1273,7 @@ bool check_common(const void *acts, const int *labels, const int *act_lens, cons
                   int V, int B, const void *ws, const rnntOptions &o) {
     if (!acts || !act_lens || !label_lens || !ws) return false;
     if (!labels && o.maxU > 1) return false;
-    if (V <= 0 || B <= 0 || o.maxT <= 0 || o.maxU <= 0 || o.maxU > 512) return false;
+    if (V <= 0 || B <= 0 || o.maxT <= 0 || o.maxU <= 0 || o.maxU > kMaxLatticeColumns) return false;
     if (o.blank_label < 0 || o.blank_label >= V) return false;
     if (o.dtype < RNNT_DTYPE_F32 || o.dtype > RNNT_DTYPE_F16) return false;
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return false;
@@ -1438,7 +1506,10 @@ rnntStatus_t launch_k2(const int *act_lens, const int *label_lens, int B, float 
         case 6: K2(6); break;
         case 7: K2(7); break;
         case 8: K2(8); break;
-        default: return RNNT_STATUS_INVALID_VALUE;  // maxU > 512: not supported
+        default:  // more than 512 columns
+            if (L.US > kMaxLatticeColumns) return RNNT_STATUS_INVALID_VALUE;
+            hipLaunchKernelGGL(rnnt_k2_lattice_wide, dim3(B), dim3(1024), (size_t)4 * L.US * sizeof(float), st, L, costs,
+                               act_lens, label_lens, o.maxT, o.maxU);
     }
 #undef K2
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
@@ -1487,7 +1558,7 @@ int rnnt_mi355_abi_version(void) { return kAbiVersion; }
 
 rnntStatus_t rnnt_get_workspace_size(int maxT, int maxU, int minibatch, size_t *size_bytes) {
     if (!size_bytes || maxT <= 0 || maxU <= 0 || minibatch <= 0) return RNNT_STATUS_INVALID_VALUE;
-    if (maxU > 512) return RNNT_STATUS_INVALID_VALUE;
+    if (maxU > kMaxLatticeColumns) return RNNT_STATUS_INVALID_VALUE;
     *size_bytes = (6 * plane_floats(maxT, maxU, minibatch) + ll_floats(minibatch)) * sizeof(float) + spans_bytes(minibatch);
     return RNNT_STATUS_SUCCESS;
 }

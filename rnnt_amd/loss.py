@@ -30,7 +30,7 @@ from . import _lib, _torch_binding
 _DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _REDUCTIONS = {"none": _lib.REDUCTION_NONE, "mean": _lib.REDUCTION_MEAN, "sum": _lib.REDUCTION_SUM}
 
-MAX_LATTICE_COLUMNS = 512  # maxU = U + 1 the library accepts (include/rnnt_mi355.h)
+MAX_LATTICE_COLUMNS = 4096  # maxU = U + 1 the library accepts (include/rnnt_mi355.h: RNNT_MAX_LATTICE_COLUMNS)
 
 # bench.py sets these to _lib.StageEvents instances to time K1/K2/K3 with hipEvents recorded by
 # the library on the launch stream.  None in normal use.
@@ -99,8 +99,8 @@ def certify_inputs(acts, labels, act_lens, label_lens, check_lengths=True):
     if labels.shape[1] != acts.shape[2] - 1:
         raise ValueError("Output length mismatch")  # labels must be [B, U] for acts [B, T, U+1, V]
     if acts.shape[2] > MAX_LATTICE_COLUMNS:
-        # a limit upstream does not have (the alpha/beta kernel holds one lattice column per lane of at most
-        # 8 waves).  ValueError, not the C ABI's RuntimeError: the reference's loop takes every RuntimeError
+        # a limit upstream does not have (the wide alpha/beta kernel keeps two anti-diagonals per direction in
+        # 64 KiB of LDS).  ValueError, not the C ABI's RuntimeError: the reference's loop takes every RuntimeError
         # for an out-of-memory condition and retries utterance by utterance (bin/train.py:80-91).
         raise ValueError("rnnt_amd supports at most {} labels per utterance (acts.shape[2] <= {}), got "
                          "acts.shape[2] = {}".format(MAX_LATTICE_COLUMNS - 1, MAX_LATTICE_COLUMNS, acts.shape[2]))

@@ -46,11 +46,11 @@ def test_shipped_library_does_not_read_the_environment():
     assert "getenv" not in syms
 
 
-def test_lattices_wider_than_512_columns_are_a_value_error_before_any_launch():
-    acts = torch.zeros(1, 2, 514, 3)
-    with pytest.raises(ValueError, match="at most 511 labels"):
-        rnnt_amd.rnnt_loss(acts, torch.ones(1, 513, dtype=torch.int32), torch.full((1,), 2, dtype=torch.int32),
-                           torch.full((1,), 513, dtype=torch.int32))
+def test_lattices_wider_than_4096_columns_are_a_value_error_before_any_launch():
+    acts = torch.zeros(1, 2, 4098, 3)
+    with pytest.raises(ValueError, match="at most 4095 labels"):
+        rnnt_amd.rnnt_loss(acts, torch.ones(1, 4097, dtype=torch.int32), torch.full((1,), 2, dtype=torch.int32),
+                           torch.full((1,), 4097, dtype=torch.int32))
 
 
 def test_workspace_size():
@@ -62,7 +62,8 @@ def test_workspace_size():
     lib = _lib.load()
     sz = ctypes.c_size_t(0)
     assert lib.rnnt_get_workspace_size(0, 41, 32, ctypes.byref(sz)) == 2       # invalid value
-    assert lib.rnnt_get_workspace_size(400, 600, 32, ctypes.byref(sz)) == 2    # maxU > 512 unsupported
+    assert lib.rnnt_get_workspace_size(400, 600, 32, ctypes.byref(sz)) == 0    # beyond 512 columns: the wide K2
+    assert lib.rnnt_get_workspace_size(400, 4097, 32, ctypes.byref(sz)) == 2   # maxU > 4096 unsupported
     assert lib.get_workspace_size(400, 41, 32, 0, ctypes.byref(sz)) == 2       # gpu=false: no CPU path
     assert lib.get_workspace_size(400, 41, 32, 1, ctypes.byref(sz)) == 0 and sz.value == n
     assert lib.rnnt_get_workspace_size(400, 41, 32, None) == 2

@@ -88,25 +88,68 @@ def test_wide_lattices_multi_wave_k2(U):
                        label=f"wide lattice U={U}")
 
 
+@pytest.mark.parametrize("U,T,ragged", [(512, 5, True), (600, 9, True), (1030, 3, False), (2500, 4, True), (4095, 2, False)])
+def test_lattices_beyond_512_columns_take_the_wide_k2(U, T, ragged):
+    """More than 511 labels (upstream has no limit): rnnt_k2_lattice_wide, 1024 threads per utterance, several
+    columns per thread, previous anti-diagonal in LDS.  Same bar as every other lattice."""
+    import rnnt_amd
+
+    acts, labels, al, ll = make_case(2, T, U, 8, seed=U, ragged=ragged, min_U=U // 2)
+    a = d(acts).requires_grad_(True)
+    costs = rnnt_amd.RNNTLoss(reduction="none")(a, d(labels), d(al), d(ll))
+    costs.backward(torch.ones_like(costs))
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), c, rtol=1e-5)
+    _, g64, _ = oracle.rnnt_loss_c(acts, labels, al, ll, dtype=np.float64)
+    got = a.grad.cpu().numpy()
+    e_gpu, e_cpu = float(np.abs(got - g64).max()), float(np.abs(g - g64).max())
+    if e_cpu <= 2e-5:
+        assert np.abs(got - g).max() <= 1e-4
+    else:
+        # |ll| is in the thousands here (V = 8, thousands of labels): one fp32 ulp of alpha + beta - ll is ~1e-3,
+        # and the fp32 ORACLE is that far from float64 (1.3e-2 at U = 4095).  The kernel may be no further.
+        assert e_gpu <= 1.5 * e_cpu + 1e-4, (e_gpu, e_cpu)
+
+
+def test_wide_and_fast_k2_give_the_same_bits():
+    """A 300-label lattice through both lattice kernels: the tensor is padded to 600 columns for the wide one."""
+    import rnnt_amd
+
+    acts, labels, al, ll = make_case(3, 11, 300, 8, seed=4, ragged=True, min_U=100)
+    crit = rnnt_amd.RNNTLoss(reduction="none")
+    a = d(acts).requires_grad_(True)
+    c0 = crit(a, d(labels), d(al), d(ll))
+    c0.sum().backward()
+    wide = np.full((3, 11, 601, 8), np.nan, np.float32)      # padding content must not matter
+    wide[:, :, :301] = acts
+    lab = np.zeros((3, 600), np.int32)
+    lab[:, :300] = labels
+    a1 = d(wide).requires_grad_(True)
+    c1 = crit(a1, d(lab), d(al), d(ll))
+    c1.sum().backward()
+    assert torch.equal(c0, c1)
+    assert torch.equal(a.grad, a1.grad[:, :, :301]) and not a1.grad[:, :, 301:].any()
+
+
 def test_too_wide_lattice_is_an_error_not_a_fault():
     import rnnt_amd
 
-    a = torch.zeros((1, 2, 514, 4), device=DEV)
-    lab = torch.ones((1, 513), dtype=torch.int32, device=DEV)
-    al, ll = (torch.tensor([v], dtype=torch.int32, device=DEV) for v in (2, 513))
+    a = torch.zeros((1, 2, 4098, 4), device=DEV)
+    lab = torch.ones((1, 4097), dtype=torch.int32, device=DEV)
+    al, ll = (torch.tensor([v], dtype=torch.int32, device=DEV) for v in (2, 4097))
     # the operator: ValueError before any launch (a RuntimeError would send the reference's loop into its
     # out-of-memory retry, bin/train.py:80-91)
-    with pytest.raises(ValueError, match="at most 511 labels"):
+    with pytest.raises(ValueError, match="at most 4095 labels"):
         rnnt_amd.RNNTLoss()(a, lab, al, ll)
     # the C ABI underneath: a status
     from rnnt_amd import _lib
     import ctypes
 
     n = ctypes.c_size_t(0)
-    assert _lib.load().rnnt_get_workspace_size(2, 514, 1, ctypes.byref(n)) == 2
+    assert _lib.load().rnnt_get_workspace_size(2, 4098, 1, ctypes.byref(n)) == 2
     costs = torch.empty(1, device=DEV)
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
-    opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, 2, 514, _lib.DTYPE_F32, None)
+    opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, 2, 4098, _lib.DTYPE_F32, None)
     assert _lib.load().rnnt_forward(a.data_ptr(), lab.data_ptr(), al.data_ptr(), ll.data_ptr(), 4, 1,
                                     costs.data_ptr(), None, 0, ws.data_ptr(), opts) == 2
 
