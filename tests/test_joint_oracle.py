@@ -93,3 +93,13 @@ def test_restated_greedy_loop_reproduces_the_reference_recognize():
             lambda e, d: joint_logits(e.view(1, 1, -1), d.view(1, 1, -1), *jp).view(-1))
         assert got == want, i
         assert m >= margin * 0.99
+
+
+@pytest.mark.parametrize("vocab,count", [(4232, 2499208), (4234, 2500234)])
+def test_parameter_count_matches_the_reference_training_log(vocab, count):
+    """The reference's own log records its JointNet's size: "# the number of parameters in the JointNet: 2499208"
+    (egs/aishell/exp/4blstm_320henc_1l512dec/train.log:14, V = 4232) and 2500234 (:47, V = 4234), for
+    JointNet(input_size=640, inner_dim=512) of config/aishell.yaml:36-39."""
+    import rnnt_amd
+
+    assert sum(p.numel() for p in rnnt_amd.JointNet(640, 512, vocab).parameters()) == count
