@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/rnnt_mi355.h"
 #include "elem_types.h"
 #include "lattice.h"
@@ -44,6 +46,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 #endif
 #ifndef FUSED_PF
 #define FUSED_PF 4
+#endif
+#ifndef FUSED_NO_VSPLIT
+#define FUSED_NO_VSPLIT 0  // 1: developer A/B build without the shared surplus row tiles (tools/build_fused_variants.sh)
 #endif
 #ifndef FUSED_STORE_AUX
 #define FUSED_STORE_AUX 0  // cache policy of the logits stores: 16 = sc1, 2 = nt, 0 = default
@@ -351,7 +356,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
                         const float *__restrict__ bias, typename DT::elem *__restrict__ logits,
                         const int *__restrict__ labels, const int *__restrict__ act_lens,
                         const int *__restrict__ label_lens, Lattice L, int maxT, int U1, int V, int blank,
-                        long long total_rows) {
+                        long long total_rows, long long row_tile0, int vsplit, float2 *__restrict__ partial) {
     typedef TileBuf<H> TB;
     typedef typename Mma<DT>::frag frag;
     typedef typename DT::elem E;
@@ -363,9 +368,15 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const bool lead = wave < kWaves / 2;  // waves 0-3 multiply first
     const int r = lane & 31, h = lane >> 5;
-    const long long my_row = (long long)blockIdx.x * kBM + wave * kRowsPerWave + r;
+    // vsplit = 1: workgroup b owns row tile row_tile0 + b and walks the whole vocabulary.  vsplit = S > 1 (the
+    // surplus row tiles of a launch that does not fill a whole round of CUs): S workgroups share a row tile, each
+    // walks 1/S of the vocabulary tiles and leaves its {max, sum} per node in `partial` for rnnt_fused_merge.
+    const long long row_tile = row_tile0 + blockIdx.x / vsplit;
+    const int split = blockIdx.x % vsplit;
+    const long long my_row = row_tile * kBM + wave * kRowsPerWave + r;
     const long long ld_row = my_row < total_rows ? my_row : total_rows - 1;
-    const int ntiles = (V + kBN - 1) / kBN;
+    const int ntiles_all = (V + kBN - 1) / kBN;
+    const int n0 = (int)((long long)split * ntiles_all / vsplit), ntiles = (int)((long long)(split + 1) * ntiles_all / vsplit);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     // this wave's 32 hidden vectors: B operand, k-step s = elements [16 s + 8 h, +8) of row l & 31
@@ -379,7 +390,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     // tile_mma: this lane's weight row (l & 31) inside a tile buffer, + 16 h for its half of a k-step
     const unsigned arow = (unsigned)((r / TB::kRPP) * TB::kPiecePitch + (r % TB::kRPP) * (H * 2) + 16 * h);
 
-    if (!lead) stage_tile<DT, H>(weight, bias, 0, lds0, part, lane);
+    if (!lead) stage_tile<DT, H>(weight, bias, min(n0 * kBN, V - kBN), lds0, part, lane);
 
     RowStat st = {-INFINITY, 0.0f};
     E *out_row = logits + (size_t)ld_row * (size_t)V;
@@ -389,7 +400,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
         sl.xw = xbuf + r * kXPitch + 8 * h;
         sl.xr = xbuf + (lane >> 2) * kXPitch + (lane & 3) * 16;
         sl.voff = (unsigned)((wave * kRowsPerWave + (lane >> 2)) * V * 2 + (lane & 3) * 16);
-        const long long wg_row0 = (long long)blockIdx.x * kBM;
+        const long long wg_row0 = row_tile * kBM;
         const long long wg_rows = total_rows - wg_row0 < kBM ? total_rows - wg_row0 : kBM;
         sl.base = reinterpret_cast<char *>(logits) + (size_t)wg_row0 * V * 2;
         sl.nbytes = (unsigned)(wg_rows * V * 2);
@@ -409,18 +420,18 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     // n-1) and run the epilogue of tile n-1.  Second half: waves 0-3 run the epilogue of tile n, waves 4-7
     // multiply tile n.  The DMAs have the whole step to land; their issuers wait for them before the barrier
     // that ends the step.  Stores need no wait at all.
-    for (int n = 0; n < ntiles; ++n) {
-        const unsigned buf = lds0 + (n & 1) * TB::kBytes;
+    for (int n = n0; n < ntiles; ++n) {
+        const unsigned buf = lds0 + ((n - n0) & 1) * TB::kBytes;
         STAMP(0);
         if (lead) {
             tile_mma<DT, H>(buf + arow, buf + TB::kWBytes + 16 * h, hid, acc);
         } else {
 #ifndef FUSED_ABLATE_DMA
             if (n + 1 < ntiles)
-                stage_tile<DT, H>(weight, bias, min((n + 1) * kBN, V - kBN), lds0 + ((n + 1) & 1) * TB::kBytes, part,
+                stage_tile<DT, H>(weight, bias, min((n + 1) * kBN, V - kBN), lds0 + ((n + 1 - n0) & 1) * TB::kBytes, part,
                                   lane);
 #endif
-            if (n > 0) tile_epilogue<DT, ALIGNED>(acc, st, out_row, sl, n - 1, V, h);
+            if (n > n0) tile_epilogue<DT, ALIGNED>(acc, st, out_row, sl, n - 1, V, h);
         }
         STAMP(1);
         asm volatile("s_barrier" ::: "memory");
@@ -452,8 +463,12 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     S += (s_o == 0.0f) ? 0.0f : s_o * __builtin_amdgcn_exp2f((finite_or_zero(m_o) - MM) * kLog2e);
     // (lane l adds its own share first, lane l+32 the other's first: only lanes 0-31 write, so the order is fixed)
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores of its 32 rows are complete
     const bool row_ok = my_row < total_rows;
+    if (vsplit > 1) {  // workgroup-uniform: a share of the vocabulary only; rnnt_fused_merge finishes the node
+        if (row_ok && h == 0) partial[(size_t)(my_row - row_tile0 * kBM) * vsplit + split] = make_float2(M, S);
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores of its 32 rows are complete
     const RowCoord c = decode_row(ld_row, maxT, U1);
     const int Tb = act_lens[c.b];
     const int Ub = label_lens[c.b];
@@ -477,6 +492,65 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     }
 }
 
+// Finishes the nodes whose vocabulary was shared by `vsplit` workgroups: combines their {max, sum} pairs (one per
+// lane, butterfly reductions: a fixed order), gathers the blank and label logits from the stored row and writes
+// the lattice planes, as the tail of rnnt_fused_proj_k1 does for a node one workgroup walked alone.  One wave per node.
+template <typename DT>
+__global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict__ partial, int vsplit, long long row0,
+                                                        long long total_rows,
+                                                        const typename DT::elem *__restrict__ logits,
+                                                        const int *__restrict__ labels,
+                                                        const int *__restrict__ act_lens,
+                                                        const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
+                                                        int V, int blank) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long row = row0 + (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (row >= total_rows) return;  // wave-uniform
+    const float2 *p = partial + (size_t)(row - row0) * vsplit;
+    const RowCoord c = decode_row(row, maxT, U1);
+    const int Tb = act_lens[c.b];
+    const int Ub = label_lens[c.b];
+    if (!(lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub)) return;
+    const bool emit = c.u < Ub;
+    const int y = emit ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
+    const bool y_ok = y >= 0 && y < V;
+    const typename DT::elem *out_row = logits + (size_t)row * (size_t)V;
+    const float xb = DT::to_float(out_row[blank]);
+    const float xy = y_ok ? DT::to_float(out_row[y]) : __builtin_nanf("");
+
+    float M = -INFINITY;
+    for (int i = lane; i < vsplit; i += kWave) M = fmaxf(M, p[i].x);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) M = fmaxf(M, __shfl_xor(M, d, kWave));
+    const float MM = finite_or_zero(M);
+    float S = 0.0f;
+    for (int i = lane; i < vsplit; i += kWave) {
+        const float2 q = p[i];
+        S += (q.y == 0.0f) ? 0.0f : q.y * __builtin_amdgcn_exp2f((finite_or_zero(q.x) - MM) * kLog2e);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) S += __shfl_xor(S, d, kWave);
+    if (lane == 0) {
+        const float logs = row_log_sum(S, M);
+        const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+        L.ml[o] = make_float2(MM, logs);
+        L.lp[o] = make_float2((xb - MM) - logs, emit ? (xy - MM) - logs : -INFINITY);
+    }
+}
+
+// Compute units of the current device (the size of one round of workgroups: the kernel runs one per CU).
+int compute_units() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 template <typename DT, int H>
 rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *bias, void *logits,
                           const int *labels, const int *act_lens, const int *label_lens, int V, int B,
@@ -487,13 +561,46 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
     if (grid > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const bool aligned = V % 8 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0;
+    // One workgroup per CU at a time: `grid` row tiles take ceil(grid / CUs) rounds, and a last round with few
+    // tiles costs as much as a full one (config 2: 2050 tiles on 256 CUs = 8 rounds + 2 tiles, +11 %).  The
+    // surplus tiles (up to half a round) are therefore launched apart, their vocabulary shared by as many
+    // workgroups as fill the round (and as the scratch holds); the {max, sum} pairs go through the alpha and beta
+    // planes, which K2 only writes later.
+    const int cus = compute_units();
+    const int ntiles = (V + kBN - 1) / kBN;
+    long long full = grid / cus * cus, surplus = grid - full;
+    int vsplit = 1;
+    if (surplus > 0 && surplus <= cus / 2) {
+        vsplit = (int)(cus / surplus);
+        if (vsplit > ntiles) vsplit = ntiles;
+        // scratch: the alpha and beta planes (adjacent in the workspace), 8 bytes per node and share
+        const size_t scratch = 2 * ((size_t)B * (L.ND + 1) * L.US + 2 * L.US) * sizeof(float);
+        const size_t fit = scratch / ((size_t)surplus * kBM * sizeof(float2));
+        if ((size_t)vsplit > fit) vsplit = (int)fit;
+    }
+    if (FUSED_NO_VSPLIT || vsplit < 2) {
+        full = grid;
+        surplus = 0;
+        vsplit = 1;
+    }
+    float2 *partial = reinterpret_cast<float2 *>(L.alpha);
 #define FUSED_ARGS                                                                                            \
     static_cast<const E *>(hidden), static_cast<const E *>(weight), bias, static_cast<E *>(logits), labels,   \
         act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
-    if (aligned)
-        hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H, true>), dim3((unsigned)grid), dim3(kThreads), 0, st, FUSED_ARGS);
-    else
-        hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H, false>), dim3((unsigned)grid), dim3(kThreads), 0, st, FUSED_ARGS);
+#define FUSED_LAUNCH(A, NWG, TILE0, SPLIT)                                                                     \
+    hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H, A>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st, FUSED_ARGS, \
+                       (long long)(TILE0), (int)(SPLIT), partial)
+    if (full > 0) {
+        if (aligned) FUSED_LAUNCH(true, full, 0, 1); else FUSED_LAUNCH(false, full, 0, 1);
+    }
+    if (surplus > 0) {
+        if (aligned) FUSED_LAUNCH(true, surplus * vsplit, full, vsplit); else FUSED_LAUNCH(false, surplus * vsplit, full, vsplit);
+        const long long row0 = full * kBM, n = rows - row0;
+        hipLaunchKernelGGL((rnnt_fused_merge<DT>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, vsplit,
+                           row0, rows, static_cast<const E *>(logits), labels, act_lens, label_lens, L, o.maxT, o.maxU, V,
+                           o.blank_label);
+    }
+#undef FUSED_LAUNCH
 #undef FUSED_ARGS
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }

@@ -96,6 +96,23 @@ def test_fused_forward_two_halves(B, T, U, V, H, dtype):
     np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("B,T,U,V,H,what", [
+    (50, 64, 15, 320, 128, "200 row tiles: less than a round of 256 CUs but more than half, every workgroup walks the whole vocabulary"),
+    (37, 112, 15, 320, 128, "259 row tiles: one full round + 3 surplus tiles whose 5 vocabulary tiles are shared by 5 workgroups each"),
+    (33, 31, 7, 4232, 256, "32 row tiles (the last one partial), each shared by 8 workgroups of 8-9 vocabulary tiles"),
+    (3, 43, 5, 16390, 128, "4 row tiles x 64 shares of a 257-tile vocabulary whose last tile overlaps"),
+])
+def test_surplus_row_tiles_share_their_vocabulary(B, T, U, V, H, what):
+    """A launch's row tiles beyond whole rounds of CUs are split along the vocabulary (rnnt_fused_merge combines the
+    {max, sum} pairs): same logits, same costs, on either side of every boundary of that rule."""
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, H, torch.bfloat16, seed=B + V)
+    st, logits, costs, _ = forward_c_abi(hidden, weight, bias, labels, al, ll)
+    assert st == 0, what
+    check_logits(logits, hidden, weight, bias)
+    c, _, _ = oracle.rnnt_loss_c(logits.float().cpu().numpy(), labels, al, ll, want_grads=False)
+    np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5, atol=0, err_msg=what)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
 def test_fused_operator_forward_backward(dtype, reduction):
