@@ -126,10 +126,14 @@ __device__ __forceinline__ void store_inside_row(const u32x4 &v, u32x4 *p, int f
     if (mis && cvt && nch == 10 && wpr == 1) w = 5;  // 13 spilled registers at 6
     return w;
 }
-[[maybe_unused]] constexpr int k3_waves(int nch, int epc) {
+[[maybe_unused]] constexpr int k3_waves(int nch, int epc, bool mis) {
     // up to 4 chunks per lane every type fits 64 VGPRs since short rows are read through a buffer
     // descriptor (fp16 V=1000: 1.69 -> 1.46 ms at 8 waves); 6 chunks per lane measured 1-2 % better
     // at 5 waves than at 6
+    // 16-bit aligned rows of 9-12 chunks per lane (bf16/fp16 V = 4232 ... 6000): 2 waves measured 1.595 -> 1.546 ms
+    // (bf16 V=4232), 1.583 -> 1.513 (fp16), 1.845 -> 1.750 (fp16 V=5000); fp32 (V=2600, 3000) and rows that are
+    // not 16-byte aligned (bf16 V=4234: 1.555 -> 1.623) keep 3; 4 and 5 waves spill (1.90 / 2.60 ms)
+    if (nch == 12 && epc > 4 && !mis) return 2;
     return nch >= 16 ? 2 : nch >= 12 ? 3 : nch >= 8 ? 4 : nch >= 6 ? 5 : 8;
 }
 template <typename DT>
@@ -1005,7 +1009,7 @@ __device__ __forceinline__ void st16(const u32x4 &v, u32x4 *p) {
 }
 
 template <typename DT, int NCH, bool MIS = false, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH, DT::EPC), k3_waves(NCH, DT::EPC))))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(k3_waves(NCH, DT::EPC, MIS), k3_waves(NCH, DT::EPC, MIS))))
 void rnnt_k3_grad(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
     const int *__restrict__ labels, const int *__restrict__ act_lens,
