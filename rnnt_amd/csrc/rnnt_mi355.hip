@@ -124,6 +124,8 @@ __device__ __forceinline__ void store_inside_row(const u32x4 &v, u32x4 *p, int f
     // waves allow (V=8201: K1 0.79 ms at 3 waves, 0.99 ms with 4-15 spilled registers at 4)
     if (mis && cvt && nch >= 16 && wpr == 1) w = 3;
     if (mis && cvt && nch == 10 && wpr == 1) w = 5;  // 13 spilled registers at 6
+    // 16-bit aligned rows with 10 chunks per lane (bf16 V=4232): 3 / 4 / 5 / 6 / 7 waves measured 0.93 / 0.82 / 0.74 /
+    // 0.70 / 0.69 ms (fp16 0.93 / 0.83 / 0.76 / 0.72 / 0.71; bf16 V=5000 1.00 / 0.88 / 0.82 / 0.81 / 0.82): stays at 6
     return w;
 }
 [[maybe_unused]] constexpr int k3_waves(int nch, int epc, bool mis) {
