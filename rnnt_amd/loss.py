@@ -108,22 +108,33 @@ def certify_inputs(acts, labels, act_lens, label_lens, check_lengths=True):
         _validate_lengths(*_start_length_fetch(acts, act_lens, label_lens))
 
 
+_copy_streams = {}  # device index -> the side stream the length check copies on
+
+
 def _start_length_fetch(acts, act_lens, label_lens):
     """Enqueue a copy of both length vectors to pinned host memory; returns what the check needs.
 
-    Upstream synchronises on ``torch.max(lengths)`` before its native call.  Here the copy is
-    enqueued BEFORE the kernels and waited for AFTER they are launched, so the host check never
-    drains the stream (the kernels guard themselves against bad lengths, so launching first is safe).
+    Upstream synchronises on ``torch.max(lengths)`` before its native call.  Here the two copies run on a side
+    stream (ordered behind whatever produced the lengths on the current one) and are waited for AFTER the kernels
+    are launched: the launch stream carries no extra work and the host check never drains it (the kernels guard
+    themselves against bad lengths, so launching first is safe).
     """
     B = acts.shape[0]
-    lens = torch.cat((act_lens.reshape(-1), label_lens.reshape(-1)))
-    if lens.is_cuda:
+    if act_lens.is_cuda:
+        dev = act_lens.device
+        side = _copy_streams.get(dev.index)
+        if side is None:
+            side = _copy_streams.setdefault(dev.index, torch.cuda.Stream(device=dev))
         host = torch.empty(2 * B, dtype=torch.int32, pin_memory=True)
-        host.copy_(lens, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(lens.device))
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            host[:B].copy_(act_lens.reshape(-1), non_blocking=True)
+            host[B:].copy_(label_lens.reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        # (act_lens / label_lens stay referenced by the caller until _validate_lengths has waited for `ev`)
     else:
-        host, ev = lens, None
+        host, ev = torch.cat((act_lens.reshape(-1), label_lens.reshape(-1))), None
     return host, ev, B, acts.shape[1], acts.shape[2]
 
 
