@@ -21,6 +21,11 @@ from . import _lib
 from .loss import _DTYPES, _REDUCTIONS, MAX_LATTICE_COLUMNS
 
 SUPPORTED_HIDDEN = (128, 256, 512)
+# Below this many lattice nodes B*T*(U+1) the fused kernel loses to the library GEMM + the three-pass loss on the
+# same device: a workgroup walks the vocabulary tile by tile, and with few row tiles that chain (0.1-0.2 ms) is
+# all there is.  Measured crossover at V=4232, H=512 (tools/bench_fused.py): 4 200 nodes 0.128 ms fused against
+# 0.105 ms unfused, 33 600 nodes 0.269 against 0.297 (profiles/r02_bench_fused_B1.json).
+DEFAULT_MIN_NODES = 16384
 
 
 class _FusedJointLossFunction(torch.autograd.Function):
@@ -82,8 +87,13 @@ class _FusedJointLossFunction(torch.autograd.Function):
         return g_hidden, g_weight, g_bias, None, None, None, None, None
 
 
-def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean"):
+def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean",
+                     min_nodes=DEFAULT_MIN_NODES):
     """``RNNTLoss(blank, reduction)(hidden @ weight.T + bias, labels, act_lens, label_lens)`` in one pass.
+
+    Lattices of fewer than ``min_nodes`` nodes (``B*T*(U+1)``) are computed as exactly that composition instead
+    — the library GEMM and ``rnnt_amd.rnnt_loss`` on the same device, which is the faster forward there
+    (``DEFAULT_MIN_NODES``); ``min_nodes=0`` always runs the fused kernel.
 
     Args:
         hidden: ``[B, T, U+1, H]`` bf16 or fp16, contiguous: what ``JointNet``'s ``Tanh`` returns
@@ -131,6 +141,11 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         hidden = hidden.contiguous()
     if not weight.is_contiguous():
         weight = weight.contiguous()
+    if B * T * U1 < min_nodes:
+        from .loss import rnnt_loss
+
+        logits = torch.nn.functional.linear(hidden, weight, bias.to(hidden.dtype))
+        return rnnt_loss(logits, labels, act_lens, label_lens, blank=blank, reduction=reduction, check_lengths=False)
     return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction)
 
 
@@ -138,13 +153,14 @@ class FusedJointLoss(torch.nn.Module):
     """``Linear(H -> V)`` of the joint network + ``RNNTLoss`` as one module; owns no parameters: pass the
     projection (``joint.mlp[2]`` of the reference's or this package's ``JointNet``) at call time."""
 
-    def __init__(self, blank: int = 0, reduction: str = "mean"):
+    def __init__(self, blank: int = 0, reduction: str = "mean", min_nodes: int = DEFAULT_MIN_NODES):
         super().__init__()
         if reduction not in _REDUCTIONS:
             raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
         self.blank = blank
         self.reduction = reduction
+        self.min_nodes = min_nodes  # smaller lattices take the library GEMM + RNNTLoss (see fused_joint_loss)
 
     def forward(self, hidden, projection: torch.nn.Linear, labels, act_lens, label_lens):
         return fused_joint_loss(hidden, projection.weight, projection.bias, labels, act_lens, label_lens,
-                                self.blank, self.reduction)
+                                self.blank, self.reduction, self.min_nodes)

@@ -127,7 +127,7 @@ def test_fused_operator_forward_backward(dtype, reduction):
     w = weight.to(DEV).requires_grad_(True)
     b = bias.to(DEV).requires_grad_(True)
     lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
-    loss = rnnt_amd.fused_joint_loss(h, w, b, lab, ald, lld, reduction=reduction)
+    loss = rnnt_amd.fused_joint_loss(h, w, b, lab, ald, lld, reduction=reduction, min_nodes=0)   # the kernel, whatever the size
     go = 0.5 if reduction != "none" else np.linspace(0.25, 1.5, B).astype(np.float32)
     loss.backward(torch.as_tensor(go, dtype=torch.float32, device=DEV).reshape(loss.shape))
 
@@ -158,9 +158,32 @@ def test_fused_equals_unfused_operator_on_device():
     hidden, weight, bias, labels, al, ll = make_inputs(4, 60, 10, 4232, 512, torch.bfloat16, seed=5)
     h, w, b = hidden.to(DEV), weight.to(DEV), bias.to(DEV)
     lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
-    fused = rnnt_amd.FusedJointLoss()(h, _Proj(w, b), lab, ald, lld)
+    fused = rnnt_amd.FusedJointLoss(min_nodes=0)(h, _Proj(w, b), lab, ald, lld)
     unfused = rnnt_amd.RNNTLoss()(torch.nn.functional.linear(h, w, b), lab, ald, lld)
     assert abs(float(fused) - float(unfused)) <= 2e-4 * abs(float(unfused))
+
+
+def test_small_lattices_take_the_unfused_composition():
+    """Below min_nodes the operator is Linear + RNNTLoss on the device (the faster forward there): same loss and
+    gradients as the fused kernel within the 16-bit rounding of the logits, and bitwise the composition itself."""
+    import rnnt_amd
+
+    hidden, weight, bias, labels, al, ll = make_inputs(2, 20, 4, 300, 256, torch.bfloat16, seed=21)
+    lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
+    outs = []
+    for min_nodes in (rnnt_amd.fused.DEFAULT_MIN_NODES, 0):
+        h, w, b = (x.to(DEV).requires_grad_(True) for x in (hidden, weight, bias))
+        loss = rnnt_amd.FusedJointLoss(min_nodes=min_nodes)(h, _Proj(w, b), lab, ald, lld)
+        loss.backward()
+        outs.append((loss.detach(), h.grad, w.grad, b.grad))
+    assert 2 * 20 * 5 < rnnt_amd.fused.DEFAULT_MIN_NODES
+    h, w, b = (x.to(DEV).requires_grad_(True) for x in (hidden, weight, bias))
+    ref = rnnt_amd.RNNTLoss(check_lengths=False)(torch.nn.functional.linear(h, w, b), lab, ald, lld)
+    ref.backward()
+    assert torch.equal(outs[0][0], ref.detach()) and torch.equal(outs[0][1], h.grad) and torch.equal(outs[0][2], w.grad)
+    assert abs(float(outs[0][0]) - float(outs[1][0])) <= 2e-4 * abs(float(outs[1][0]))
+    for a, c in zip(outs[0][1:], outs[1][1:]):
+        assert float((a.float() - c.float()).abs().max()) <= 4 * EPS[torch.bfloat16] * float(c.float().abs().max()) + 1e-6
 
 
 class _Proj:
