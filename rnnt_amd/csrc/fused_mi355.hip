@@ -224,8 +224,10 @@ struct RowStat {
 // by group (few live registers: the kernel sits at the 256-VGPR limit of two waves per SIMD).
 // MASKED: the last tile of a vocabulary that is no multiple of 64 starts at V - 64 and overlaps its
 // predecessor; entries below `vmin` were counted there and only take part in the stores (same values again).
-// ALIGNED: logits rows are 16-byte aligned (V % 8 == 0): four 16-byte stores per lane, else element stores.
-struct StoreLane {   // where this lane stores after the transpose through LDS (ALIGNED path)
+// Rows of a vocabulary that is no multiple of 8 are not 16-byte aligned: the 16-byte stores then go to 2-byte
+// aligned addresses, which the memory pipeline accepts (unaligned access mode); measured against element stores
+// from the accumulator layout: V = 4234 3.24 -> 2.81 ms, V = 5455 4.14 -> 3.50 ms.
+struct StoreLane {   // where this lane stores after the transpose through LDS
     unsigned xw;     // LDS byte address this lane WRITES its groups to: xbuf + (l & 31) * kXPitch + 8 h
     unsigned xr;     // LDS byte address it READS a 16-byte piece from: xbuf + (l >> 2) * kXPitch + (l & 3) * 16
     unsigned voff;   // byte offset in the workgroup's 256 logits rows: (32 wave + (l >> 2)) * 2V + (l & 3) * 16
@@ -235,7 +237,7 @@ struct StoreLane {   // where this lane stores after the transpose through LDS (
 };
 constexpr int kXPitch = 80;  // bytes per row of the transpose buffer: 64 of data, 16-byte aligned, 2-way banks at worst
 
-template <typename DT, bool ALIGNED, bool MASKED>
+template <typename DT, bool MASKED>
 __device__ __forceinline__ void tile_epilogue_impl(const f32x16 (&acc)[2], RowStat &st,
                                                    typename DT::elem *out_row, const StoreLane &sl, int c0,
                                                    int vmin, int V, int h) {
@@ -284,7 +286,7 @@ __device__ __forceinline__ void tile_epilogue_impl(const f32x16 (&acc)[2], RowSt
             part[q & 3] += counted(t, 2 * q + 1) ? __builtin_amdgcn_exp2f(__builtin_fmaf(hi, kLog2e, nmm2)) : 0.0f;
 #endif
         }
-        if (ALIGNED) {
+        {
             // A lane holds 16 entries of ONE node in four groups of 8 bytes; stored from here, a wave instruction
             // would scatter 64 pieces of 16 bytes over 32 rows.  The wave's 32 x 32 tile goes through its
             // private LDS buffer instead (DS instructions of one wave execute in order: no wait, no barrier)
@@ -324,12 +326,6 @@ __device__ __forceinline__ void tile_epilogue_impl(const f32x16 (&acc)[2], RowSt
                 asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
 #endif
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int v = c0 + t * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-                reinterpret_cast<unsigned short *>(out_row)[v] = (unsigned short)(pk[i >> 1] >> (16 * (i & 1)));
-            }
         }
     }
     st.s = carried + ((part[0] + part[1]) + (part[2] + part[3]));
@@ -337,20 +333,20 @@ __device__ __forceinline__ void tile_epilogue_impl(const f32x16 (&acc)[2], RowSt
 }
 
 // Tile n covers vocabulary entries c0 .. c0+63 with c0 = min(64 n, V - 64).
-template <typename DT, bool ALIGNED>
+template <typename DT>
 __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2], RowStat &st, typename DT::elem *out_row,
                                               const StoreLane &sl, int n, int V, int h) {
     const int vmin = n * kBN;
     if (vmin + kBN <= V)  // workgroup-uniform
-        tile_epilogue_impl<DT, ALIGNED, false>(acc, st, out_row, sl, vmin, vmin, V, h);
+        tile_epilogue_impl<DT, false>(acc, st, out_row, sl, vmin, vmin, V, h);
     else
-        tile_epilogue_impl<DT, ALIGNED, true>(acc, st, out_row, sl, V - kBN, vmin, V, h);
+        tile_epilogue_impl<DT, true>(acc, st, out_row, sl, V - kBN, vmin, V, h);
 }
 
 // Two waves share a SIMD (waves w and w + 4).  Waves 0-3 multiply tile n while waves 4-7 run the epilogue of
 // tile n-1, then the roles swap: the matrix pipe and the vector ALU of every SIMD are busy in both halves
 // of a step instead of both waves queueing for the same unit.
-template <typename DT, int H, bool ALIGNED>
+template <typename DT, int H>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const typename DT::elem *__restrict__ weight,
                         const float *__restrict__ bias, typename DT::elem *__restrict__ logits,
@@ -431,13 +427,13 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
                 stage_tile<DT, H>(weight, bias, min((n + 1) * kBN, V - kBN), lds0 + ((n + 1 - n0) & 1) * TB::kBytes, part,
                                   lane);
 #endif
-            if (n > n0) tile_epilogue<DT, ALIGNED>(acc, st, out_row, sl, n - 1, V, h);
+            if (n > n0) tile_epilogue<DT>(acc, st, out_row, sl, n - 1, V, h);
         }
         STAMP(1);
         asm volatile("s_barrier" ::: "memory");
         STAMP(2);
         if (lead) {
-            tile_epilogue<DT, ALIGNED>(acc, st, out_row, sl, n, V, h);
+            tile_epilogue<DT>(acc, st, out_row, sl, n, V, h);
             STAMP(3);
             asm volatile("s_barrier" ::: "memory");
         } else {
@@ -446,13 +442,16 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
             // allow exactly those stores to stay in flight (their write acknowledgements take longer than
             // a step under load; waiting for them stalled every step).
             STAMP(3);
-            if (!ALIGNED)
-                asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");  // 32 element stores per epilogue
+            // In the first step there was no epilogue: the youngest four operations ARE DMAs and must land too
+            // (seen as stale pieces of the walk's second tile, once in ~150 small launches, when many workgroups
+            // start cold at once and a DMA takes longer than the 64 MFMAs between its issue and this wait).
+            if (n == n0)
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             else
-                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // 4 16-byte stores per epilogue
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // 4 16-byte stores per epilogue
         }
     }
-    if (!lead) tile_epilogue<DT, ALIGNED>(acc, st, out_row, sl, ntiles - 1, V, h);
+    if (!lead) tile_epilogue<DT>(acc, st, out_row, sl, ntiles - 1, V, h);
     const float m = st.m, ssum = st.s;
 
     // ---- merge the two lanes of a node, gather the blank and label logits, write the lattice planes ----
@@ -560,7 +559,6 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
     const long long grid = (rows + kBM - 1) / kBM;
     if (grid > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
-    const bool aligned = V % 8 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0;
     // One workgroup per CU at a time: `grid` row tiles take ceil(grid / CUs) rounds, and a last round with few
     // tiles costs as much as a full one (config 2: 2050 tiles on 256 CUs = 8 rounds + 2 tiles, +11 %).  The
     // surplus tiles (up to half a round) are therefore launched apart, their vocabulary shared by as many
@@ -587,14 +585,12 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
 #define FUSED_ARGS                                                                                            \
     static_cast<const E *>(hidden), static_cast<const E *>(weight), bias, static_cast<E *>(logits), labels,   \
         act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
-#define FUSED_LAUNCH(A, NWG, TILE0, SPLIT)                                                                     \
-    hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H, A>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st, FUSED_ARGS, \
+#define FUSED_LAUNCH(NWG, TILE0, SPLIT)                                                                      \
+    hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st, FUSED_ARGS, \
                        (long long)(TILE0), (int)(SPLIT), partial)
-    if (full > 0) {
-        if (aligned) FUSED_LAUNCH(true, full, 0, 1); else FUSED_LAUNCH(false, full, 0, 1);
-    }
+    if (full > 0) FUSED_LAUNCH(full, 0, 1);
     if (surplus > 0) {
-        if (aligned) FUSED_LAUNCH(true, surplus * vsplit, full, vsplit); else FUSED_LAUNCH(false, surplus * vsplit, full, vsplit);
+        FUSED_LAUNCH(surplus * vsplit, full, vsplit);
         const long long row0 = full * kBM, n = rows - row0;
         hipLaunchKernelGGL((rnnt_fused_merge<DT>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, vsplit,
                            row0, rows, static_cast<const E *>(logits), labels, act_lens, label_lens, L, o.maxT, o.maxU, V,

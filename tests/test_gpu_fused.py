@@ -59,13 +59,13 @@ def forward_c_abi(hidden, weight, bias, labels, al, ll, reduction=0):
     return st, logits, costs, ws
 
 
-def check_logits(logits, hidden, weight, bias):
+def check_logits(logits, hidden, weight, bias, min_exact=0.999):
     ref64 = torch.nn.functional.linear(hidden.double(), weight.double(), bias.double())   # model.py:17,59
     ref = ref64.to(logits.dtype)
     got = logits.cpu()
     assert bool(torch.isfinite(got.float()).all()), "an element of logits_out was not written"
     exact = (got == ref).float().mean().item()
-    assert exact >= 0.999, exact
+    assert exact >= min_exact, exact
     # spacing of the dtype at the value: 2^(exponent - mantissa bits); a result on the wrong side of a rounding
     # boundary is just over half a spacing from the float64 value, anything else at most half
     mag = torch.maximum(ref64.abs(), got.double().abs()).clamp_min(2.0 ** -14)
@@ -79,7 +79,7 @@ def check_logits(logits, hidden, weight, bias):
 
 @pytest.mark.parametrize("B,T,U,V,H,dtype", [
     (2, 9, 4, 4232, 512, torch.bfloat16),      # the reference's vocabulary and inner size
-    (3, 33, 7, 4234, 512, torch.bfloat16),     # rows not 16-byte aligned: element stores
+    (3, 33, 7, 4234, 512, torch.bfloat16),     # rows not 16-byte aligned: 16-byte stores at 2-byte aligned addresses
     (2, 21, 5, 5455, 512, torch.float16),      # config/magic_*.yaml's vocabulary, odd
     (1, 40, 6, 64, 512, torch.bfloat16),       # exactly one tile
     (2, 17, 3, 100, 256, torch.bfloat16),      # last tile overlaps its predecessor; H = 256
@@ -111,6 +111,21 @@ def test_surplus_row_tiles_share_their_vocabulary(B, T, U, V, H, what):
     check_logits(logits, hidden, weight, bias)
     c, _, _ = oracle.rnnt_loss_c(logits.float().cpu().numpy(), labels, al, ll, want_grads=False)
     np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5, atol=0, err_msg=what)
+
+
+@pytest.mark.parametrize("B,T,U,V,H,dtype", [(3, 1, 6, 518, 512, torch.float16), (5, 11, 5, 880, 128, torch.bfloat16),
+                                             (7, 39, 7, 2584, 128, torch.float16)])
+def test_repeated_small_launches_give_the_same_bits(B, T, U, V, H, dtype):
+    """Regression: the first step of a vocabulary walk once let its last four weight-tile DMAs stay in flight past the
+    barrier (no epilogue stores had been issued yet to be the youngest operations), and about one small launch in
+    150 — many workgroups starting cold at once — multiplied a half-landed second tile.  300 launches each."""
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, H, dtype, seed=V)
+    st, first, costs0, _ = forward_c_abi(hidden, weight, bias, labels, al, ll)
+    assert st == 0
+    check_logits(first, hidden, weight, bias, min_exact=0.995)   # (10 878 fp16 logits: a dozen sit on rounding boundaries)
+    for i in range(300):
+        st, logits, costs, _ = forward_c_abi(hidden, weight, bias, labels, al, ll)
+        assert st == 0 and torch.equal(logits, first) and torch.equal(costs, costs0), f"launch {i} differs"
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
