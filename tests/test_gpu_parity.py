@@ -297,3 +297,27 @@ def test_plus_inf_logit_generic_kernel():
                                                torch.from_numpy(al[1:]).to(dev), torch.from_numpy(ll[1:]).to(dev))
     loss = loss.cpu().numpy()
     assert np.isfinite(loss[0]) and np.isnan(loss[1])
+
+
+@pytest.mark.parametrize("B,T,U,V,dtype", [(64, 12, 5, 4232, torch.float32), (130, 9, 4, 520, torch.float32),
+                                           (2, 6, 600, 8, torch.float32), (33, 17, 6, 4234, torch.bfloat16),
+                                           (5, 30, 7, 29, torch.float16)])
+def test_repeated_launches_give_the_same_bits(B, T, U, V, dtype):
+    """No atomics, fixed summation orders, counted waits: 150 forward+backward launches of one ragged batch (compacted
+    node order, wide lattice, rows that are not 16-byte aligned, small rows) return identical costs and gradients."""
+    import rnnt_amd
+
+    acts, labels, al, ll = make_case(B, T, U, V, seed=B + V, ragged=True, min_U=U // 2)
+    dev = torch.device("cuda:0")
+    a = torch.from_numpy(acts).to(dev).to(dtype).requires_grad_(True)
+    lab, ald, lld = (torch.from_numpy(x).to(dev) for x in (labels, al, ll))
+    crit = rnnt_amd.RNNTLoss(reduction="none", check_lengths=False)
+    first = None
+    for i in range(150):
+        a.grad = None
+        c = crit(a, lab, ald, lld)
+        c.sum().backward()
+        if first is None:
+            first = (c.detach().clone(), a.grad.clone())
+        else:
+            assert torch.equal(c.detach(), first[0]) and torch.equal(a.grad, first[1]), f"launch {i} differs"
