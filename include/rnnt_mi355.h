@@ -186,7 +186,9 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
  * rnnt_backward(logits_out, ...) afterwards is exactly the backward of rnnt_forward(logits_out, ...).
  * options.dtype: RNNT_DTYPE_BF16 or RNNT_DTYPE_F16 (fp32 accumulation; fp32 operands are not taken: the
  * fp32 matrix rate is 1/16 of the 16-bit one); hidden_size: 128, 256 or 512; hidden and weight
- * 16-byte aligned.  INVALID_VALUE otherwise.
+ * 16-byte aligned; alphabet_size >= 64 (one tile), any value above, rows of logits_out need no alignment beyond
+ * the element's.  INVALID_VALUE otherwise.  (Inside the call the alpha and beta planes of `workspace` hold partial
+ * softmax statistics of row tiles whose vocabulary several workgroups share, until K2 writes the planes.)
  */
 rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, const float *bias,
                                      void *logits_out, const int *labels, const int *act_lens,
