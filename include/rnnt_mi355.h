@@ -197,6 +197,36 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
                                      void *workspace, rnntOptions options);
 
 /*
+ * Backward of the pair above with K3 as the PROLOGUE of the projection's two backward products: replaces what
+ * autograd runs behind /root/reference/src/rnnt/model.py:17,59 and :116 when bin/train.py:43 calls
+ * loss.backward() — the loss's gradient w.r.t. the logits (rnnt_backward: a [B,T,U1,V] tensor written once)
+ * followed by grad_hidden = g W and grad_weight = g^T hidden (each reads that tensor back).  Here the gradient
+ * w.r.t. the logits is never written: two MFMA kernels read the stored logits (logits_out of
+ * rnnt_joint_loss_forward, or any logits rnnt_forward ran on with the same workspace), form the gradient tile in
+ * registers exactly as rnnt_backward does (same operations, same rounding to options.dtype) and feed it to the
+ * matrix cores.
+ *   grad_hidden [B*T*U1, H] options.dtype   = g W                       (NULL: not computed)
+ *   grad_weight [V, H]      options.dtype   = g^T hidden                (NULL: not computed)
+ *   grad_bias   [V]         fp32            = column sums of g           (NULL: not computed)
+ * where g = grad_scale * grad_out[b * grad_out_stride] * d costs[b] / d logits, rounded to options.dtype
+ * (grad_out, grad_out_stride, grad_scale as rnnt_backward).  Sums over the lattice nodes are formed per node
+ * range and added in range order: no atomics, results are bitwise reproducible.
+ * workspace: the lattice workspace rnnt_joint_loss_forward / rnnt_forward filled.  backward_workspace: scratch of
+ * rnnt_joint_loss_backward_workspace_size bytes, 256-byte aligned (node coefficients, partial sums of
+ * grad_weight per node range).  hidden_size 512 (the reference's inner_dim), alphabet_size >= 128, 16-bit
+ * options.dtype; hidden, weight, grad_hidden 16-byte and grad_weight 8-byte aligned.  INVALID_VALUE otherwise:
+ * such callers run rnnt_backward and two library GEMMs (rnnt_amd/fused.py does).
+ * options.stage_events (optional): [0] start, [1] after the node coefficients, [2] after grad_hidden, [3] end.
+ */
+rnntStatus_t rnnt_joint_loss_backward_workspace_size(int hidden_size, int alphabet_size, int minibatch, int maxT,
+                                                     int maxU, size_t *size_bytes);
+rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, const void *logits, const int *labels,
+                                      const int *act_lens, const int *label_lens, int hidden_size,
+                                      int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
+                                      float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
+                                      const void *workspace, void *backward_workspace, rnntOptions options);
+
+/*
  * ---- greedy decoding --------------------------------------------------------
  * out[r] = first index of the maximum of row r of x[rows, V] (a NaN counts as the maximum: torch.argmax's
  * conventions).  Replaces the per-frame softmax -> argmax of the reference's greedy loop

@@ -880,15 +880,6 @@ __global__ void rnnt_reduce_costs_kernel(const float *__restrict__ costs, float 
 // Bound: HBM read N_valid + write N_full.  One wave per node.
 //   g_v = scale * ( softmax_v * (Bk + Yk)  - [v=blank] Bk - [v=y_u] Yk )
 // ---------------------------------------------------------------------------------------------
-struct NodeCoef {
-    float sa;    // scale * (Bk + Yk): weight of softmax_v
-    float sbk;   // scale * Bk: taken off the blank logit
-    float syk;   // scale * Yk: taken off the label logit
-    float m, l;  // softmax_v = 2^((x_v - m)*log2e - l*log2e): x - max first (as torch.log_softmax), so a
-                 // large common offset of the logits costs nothing
-    int y;       // label of this node's emit arc, -1 if none
-};
-
 // Same association as the upstream CPU path: alpha + beta_next + lp - ll, and the dense softmax
 // term weighted by (Bk + Yk) rather than by e^{alpha+beta-ll}.
 __device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &c, int Tb, int Ub,
@@ -914,44 +905,6 @@ __device__ __forceinline__ NodeCoef node_coef(const Lattice &L, const RowCoord &
     const float2 ml = L.ml[o];
     n.m = ml.x;
     n.l = ml.y;
-    n.sa = scale * (bk + yk);
-    n.sbk = scale * bk;
-    n.syk = scale * yk;
-    return n;
-}
-
-// The same in two steps for kernels that handle several nodes per lane: every value node_coef reads,
-// loaded unconditionally (nothing here depends on another load), then the arithmetic.
-struct NodeIn {
-    float llb, a, go, beta_t, beta_u;
-    float2 lp, ml;
-};
-__device__ __forceinline__ NodeIn node_in(const Lattice &L, const RowCoord &c, bool emit,
-                                          const float *__restrict__ grad_out, int grad_out_stride) {
-    const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
-    NodeIn in;
-    in.llb = L.ll[c.b];
-    in.a = L.alpha[o];
-    in.lp = L.lp[o];
-    in.ml = L.ml[o];
-    in.go = grad_out ? grad_out[(size_t)c.b * grad_out_stride] : 1.0f;
-    in.beta_t = L.beta[o + L.US];                 // next diagonal (the last one is followed by K2's junk row)
-    in.beta_u = L.beta[o + L.US + (emit ? 1 : 0)];  // column u+1 only where it exists
-    return in;
-}
-__device__ __forceinline__ NodeCoef node_coef_from(const NodeIn &in, int t, int u, int Tb, int Ub, int y,
-                                                   float grad_scale) {
-    const float scale = grad_scale * in.go;
-    float bk = 0.0f, yk = 0.0f;
-    if (t < Tb - 1)
-        bk = __expf(in.a + in.beta_t + in.lp.x - in.llb);
-    else if (u == Ub)
-        bk = __expf(in.a + in.lp.x - in.llb);
-    if (u < Ub) yk = __expf(in.a + in.beta_u + in.lp.y - in.llb);
-    NodeCoef n;
-    n.y = u < Ub ? y : -1;
-    n.m = in.ml.x;
-    n.l = in.ml.y;
     n.sa = scale * (bk + yk);
     n.sbk = scale * bk;
     n.syk = scale * yk;

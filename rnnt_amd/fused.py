@@ -28,9 +28,14 @@ SUPPORTED_HIDDEN = (128, 256, 512)
 DEFAULT_MIN_NODES = 16384
 
 
+def fused_backward_supported(H: int, V: int) -> bool:
+    """Shapes ``rnnt_joint_loss_backward`` takes (include/rnnt_mi355.h); others run K3 + two library GEMMs."""
+    return H == 512 and V >= 128
+
+
 class _FusedJointLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction):
+    def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction, fused_backward):
         lib = _lib.load()
         B, T, U1, H = hidden.shape
         V = weight.shape[0]
@@ -53,6 +58,7 @@ class _FusedJointLossFunction(torch.autograd.Function):
         ctx.blank = int(blank)
         ctx.reduction = red
         ctx.bias_dtype = bias.dtype
+        ctx.fused_backward = bool(fused_backward)
         return loss
 
     @staticmethod
@@ -70,25 +76,46 @@ class _FusedJointLossFunction(torch.autograd.Function):
                 stride, scale = 1, 1.0
             else:
                 stride, scale = 0, (1.0 / B if ctx.reduction == _lib.REDUCTION_MEAN else 1.0)
-            g_logits = torch.empty_like(logits)
             opts = _lib.RnntOptions(stream, ctx.blank, T, U1, _DTYPES[logits.dtype], None)
-            _lib.check(lib.rnnt_backward(logits.data_ptr(), g_logits.data_ptr(), labels.data_ptr(),
-                                         act_lens.data_ptr(), label_lens.data_ptr(), V, B, go.data_ptr(), stride,
-                                         ctypes.c_float(scale), ws.data_ptr(), opts), "rnnt_backward")
-            g2 = g_logits.view(-1, V)
-            h2 = hidden.reshape(-1, H)
+            need_h, need_w, need_b = ctx.needs_input_grad[:3]
             g_hidden = g_weight = g_bias = None
-            if ctx.needs_input_grad[0]:
-                g_hidden = torch.mm(g2, weight).view_as(hidden)        # plain library GEMMs (hipBLASLt)
-            if ctx.needs_input_grad[1]:
-                g_weight = torch.mm(g2.t(), h2)
-            if ctx.needs_input_grad[2]:
-                g_bias = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
-        return g_hidden, g_weight, g_bias, None, None, None, None, None
+            if ctx.fused_backward and fused_backward_supported(H, V):
+                # K3 as the prologue of the two products: the gradient w.r.t. the logits is never written
+                n = ctypes.c_size_t(0)
+                _lib.check(lib.rnnt_joint_loss_backward_workspace_size(H, V, B, T, U1, ctypes.byref(n)),
+                           "rnnt_joint_loss_backward_workspace_size")
+                bws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
+                if need_h:
+                    g_hidden = torch.empty_like(hidden)
+                if need_w:
+                    g_weight = torch.empty_like(weight)
+                gb32 = torch.empty(V, dtype=torch.float32, device=dev) if need_b else None
+                _lib.check(lib.rnnt_joint_loss_backward(
+                    hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), labels.data_ptr(), act_lens.data_ptr(),
+                    label_lens.data_ptr(), H, V, B, go.data_ptr(), stride, ctypes.c_float(scale),
+                    g_hidden.data_ptr() if need_h else None, g_weight.data_ptr() if need_w else None,
+                    gb32.data_ptr() if need_b else None, ws.data_ptr(), bws.data_ptr(), opts),
+                    "rnnt_joint_loss_backward")
+                if need_b:
+                    g_bias = gb32.to(ctx.bias_dtype)
+            else:
+                g_logits = torch.empty_like(logits)
+                _lib.check(lib.rnnt_backward(logits.data_ptr(), g_logits.data_ptr(), labels.data_ptr(),
+                                             act_lens.data_ptr(), label_lens.data_ptr(), V, B, go.data_ptr(), stride,
+                                             ctypes.c_float(scale), ws.data_ptr(), opts), "rnnt_backward")
+                g2 = g_logits.view(-1, V)
+                h2 = hidden.reshape(-1, H)
+                if need_h:
+                    g_hidden = torch.mm(g2, weight).view_as(hidden)        # plain library GEMMs (hipBLASLt)
+                if need_w:
+                    g_weight = torch.mm(g2.t(), h2)
+                if need_b:
+                    g_bias = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        return g_hidden, g_weight, g_bias, None, None, None, None, None, None
 
 
 def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean",
-                     min_nodes=DEFAULT_MIN_NODES):
+                     min_nodes=DEFAULT_MIN_NODES, fused_backward=True):
     """``RNNTLoss(blank, reduction)(hidden @ weight.T + bias, labels, act_lens, label_lens)`` in one pass.
 
     Lattices of fewer than ``min_nodes`` nodes (``B*T*(U+1)``) are computed as exactly that composition instead
@@ -146,21 +173,24 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
 
         logits = torch.nn.functional.linear(hidden, weight, bias.to(hidden.dtype))
         return rnnt_loss(logits, labels, act_lens, label_lens, blank=blank, reduction=reduction, check_lengths=False)
-    return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction)
+    return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction,
+                                         fused_backward)
 
 
 class FusedJointLoss(torch.nn.Module):
     """``Linear(H -> V)`` of the joint network + ``RNNTLoss`` as one module; owns no parameters: pass the
     projection (``joint.mlp[2]`` of the reference's or this package's ``JointNet``) at call time."""
 
-    def __init__(self, blank: int = 0, reduction: str = "mean", min_nodes: int = DEFAULT_MIN_NODES):
+    def __init__(self, blank: int = 0, reduction: str = "mean", min_nodes: int = DEFAULT_MIN_NODES,
+                 fused_backward: bool = True):
         super().__init__()
         if reduction not in _REDUCTIONS:
             raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
         self.blank = blank
         self.reduction = reduction
         self.min_nodes = min_nodes  # smaller lattices take the library GEMM + RNNTLoss (see fused_joint_loss)
+        self.fused_backward = fused_backward  # False: K3 + two library GEMMs (the round-2 backward), for A/B runs
 
     def forward(self, hidden, projection: torch.nn.Linear, labels, act_lens, label_lens):
         return fused_joint_loss(hidden, projection.weight, projection.bias, labels, act_lens, label_lens,
-                                self.blank, self.reduction, self.min_nodes)
+                                self.blank, self.reduction, self.min_nodes, self.fused_backward)
