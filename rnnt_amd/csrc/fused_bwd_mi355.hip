@@ -40,6 +40,15 @@ using namespace rnnt_mi355_detail;
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+#ifndef FUSED_BWD_VALU_PER_MFMA
+#define FUSED_BWD_VALU_PER_MFMA 3  // 0: developer A/B build with the gradient values computed after the MFMAs
+#endif
+
+// Developer timing builds with one part removed (tools/build_bwd_variants.sh; results are wrong by design):
+//   FUSED_BWD_ABLATE_MMA    no MFMAs (fragments still read)      FUSED_BWD_ABLATE_VALU  no exp/fma on the logits
+//   FUSED_BWD_ABLATE_DMA    no LDS-DMA of the Q tiles             FUSED_BWD_ABLATE_LOAD  no logits / coefficient loads
+//   FUSED_BWD_ABLATE_READ   fragments from registers, no LDS reads
+
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * kWave;
 constexpr int kBM = 128;  // output rows per workgroup: lattice nodes (dH) or vocabulary entries (dW)
@@ -92,15 +101,19 @@ __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ o
 
 // Eight gradient values from eight stored logits: K3's grad_chunk (rnnt_mi355.hip) operation for operation —
 // x - m, fused multiply-add with log2e and -l log2e, exp2, times sa, then the two sparse corrections in K3's
-// order — so that the rounded tile equals what rnnt_backward would have written.  dy / db: position of the
-// label / blank logit relative to this chunk's first element.  The corrections are real branches (one lane in
+// order — so that the rounded tile equals what rnnt_backward would have written.  In two parts: the dense part
+// (branch-free: it is scheduled between the MFMAs of the previous tile) and the corrections.  dy / db: position of
+// the label / blank logit relative to this chunk's first element; the corrections are real branches (one lane in
 // hundreds takes them); `keep_from`: elements below it belong to the previous, overlapping tile and give 0.
 template <typename DT>
-__device__ __forceinline__ void grad8(const u32x4 &raw, float m, float nl2, float sa, float syk, float sbk, int dy, int db,
-                                      bool masked, int keep_from, float (&x)[8]) {
+__device__ __forceinline__ void grad8_main(const u32x4 &raw, float m, float nl2, float sa, float (&x)[8]) {
     DT::unpack(raw, x);
+#ifndef FUSED_BWD_ABLATE_VALU
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j] - m, kLog2e, nl2)) * sa;
+#endif
+}
+__device__ __forceinline__ void grad8_fix(float syk, float sbk, int dy, int db, bool masked, int keep_from, float (&x)[8]) {
     if ((unsigned)db < 8u) {
         asm volatile("; blank-logit correction" ::: "memory");  // keeps this a branch (see grad_chunk)
 #pragma unroll
@@ -127,47 +140,65 @@ typedef __attribute__((address_space(3))) u32x4 *lds_u128;
 typedef const __attribute__((address_space(3))) u32x4 *lds_cu128;
 
 // B fragments of one step for this wave's four 32-column tiles and the 32 MFMAs of the step.
-//   boff[jn]: this lane's byte offset inside the Q image for column tile jn, k-step 0, rows 8h + q
+//   bq[jn]: this lane's LDS address inside the Q image for column tile jn, k-step 0, rows 8h + q
 //   AFRAG(s, i): A fragment of k-step s, row tile i (differs between the two kernels)
 //   A_READS: LDS read instructions per A fragment (1: ds_read_b128, 2: transposed)
 // The fragments of k-step s + 1 are read between the MFMAs of k-step s; the order is pinned with
 // sched_group_barrier (left alone, hipcc hoists every read of the step to its top and spills the accumulators).
-template <typename DT, int A_READS, typename AFRAG>
-__device__ __forceinline__ void mma_step(unsigned qbuf, const unsigned (&boff)[4], f32x16 (&acc)[2][4], AFRAG afrag) {
+//   VALU: vector-ALU work that does not depend on this step (the dense part of the next tile's gradient values):
+//         three of its instructions go between consecutive MFMAs, where the matrix pipe leaves the issue port idle
+template <typename DT, int A_READS, typename AFRAG, typename VALU, typename KEEP>
+__device__ __forceinline__ void mma_step(const unsigned (&bq)[4], f32x16 (&acc)[2][4], AFRAG afrag, VALU valu, KEEP keep) {
     typedef typename Mma<DT>::frag frag;
     constexpr int KS = kBK / 16;
     frag a[2][2], b[2][4];  // [k-step parity]
     auto read_frags = [&](int s) {
+#ifndef FUSED_BWD_ABLATE_READ
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[s & 1][i] = afrag(s, i);
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn)
-            b[s & 1][jn] = lds_read_tr_frag<frag>(qbuf + boff[jn] + s * 16 * kQRow, 4 * kQRow);
+            b[s & 1][jn] = lds_read_tr_frag<frag>(bq[jn] + s * 16 * kQRow, 4 * kQRow);
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[s & 1][i] = __builtin_bit_cast(frag, u32x4{bq[0], bq[1], bq[2], (unsigned)(s + i)});
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) b[s & 1][jn] = __builtin_bit_cast(frag, u32x4{bq[jn], bq[1], bq[2], (unsigned)s});
+#endif
     };
     __builtin_amdgcn_sched_barrier(0);
     read_frags(0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * A_READS + 8, 0);
-    __builtin_amdgcn_s_setprio(1);
+    valu();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         if (s + 1 < KS) read_frags(s + 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) acc[i][jn] = Mma<DT>::mma(a[s & 1][i], b[s & 1][jn], acc[i][jn]);
+            for (int jn = 0; jn < 4; ++jn) {
+#ifndef FUSED_BWD_ABLATE_MMA
+                acc[i][jn] = Mma<DT>::mma(a[s & 1][i], b[s & 1][jn], acc[i][jn]);
+#else
+                asm volatile("" ::"v"(a[s & 1][i]), "v"(b[s & 1][jn]));
+#endif
+            }
         // 8 MFMAs with the next k-step's 2 A_READS + 8 reads spread between them: 2,1,x,1,2,1,x,1 (x = A_READS)
 #define MMA1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0)
 #define DSR(N) __builtin_amdgcn_sched_group_barrier(0x100, N, 0)
+#define VAL __builtin_amdgcn_sched_group_barrier(0x002, FUSED_BWD_VALU_PER_MFMA, 0)
         if (s + 1 < KS) {
-            MMA1; DSR(2); MMA1; DSR(1); MMA1; DSR(A_READS); MMA1; DSR(1);
-            MMA1; DSR(2); MMA1; DSR(1); MMA1; DSR(A_READS); MMA1; DSR(1);
+            MMA1; DSR(2); VAL; MMA1; DSR(1); VAL; MMA1; DSR(A_READS); VAL; MMA1; DSR(1); VAL;
+            MMA1; DSR(2); VAL; MMA1; DSR(1); VAL; MMA1; DSR(A_READS); VAL; MMA1; DSR(1); VAL;
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL;
         }
 #undef MMA1
 #undef DSR
+#undef VAL
     }
-    __builtin_amdgcn_s_setprio(0);
+    keep();  // (uses of the vector work's results inside this scheduling region: hipcc otherwise sinks the work into
+             // the conditional block that consumes it, behind the MFMAs)
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -236,25 +267,42 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
 #pragma unroll
         for (int i = 0; i < kBK / kWaves; ++i) {
             const int kr = wave * (kBK / kWaves) + i;
+#ifndef FUSED_BWD_ABLATE_DMA
             lds_dma16(dma_voff(lane, i & 3), src + (size_t)kr * kQRow, dst + kr * kQRow);
+#endif
         }
     };
     auto load_tile = [&](int j, u32x4 (&raw)[2]) {
         const unsigned off = j < NT ? (unsigned)(tile_c0(j) * 2) : kOob;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) raw[q] = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc, row_off[q] + off, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+#ifndef FUSED_BWD_ABLATE_LOAD
+            raw[q] = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc, row_off[q] + off, 0, 0);
+#else
+            raw[q] = u32x4{off, row_off[q], 0u, 0u};
+#endif
+        }
     };
-    auto g_tile = [&](int j, const u32x4 (&raw)[2]) {
+    float gx[2][8];  // the gradient values of the next tile, before the corrections
+    auto g_main = [&](const u32x4 (&raw)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) grad8_main<DT>(raw[q], cf[q].m, cf[q].nl2, cf[q].sa, gx[q]);
+    };
+    auto keep_gx = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            asm volatile("" ::"v"(gx[q][0]), "v"(gx[q][1]), "v"(gx[q][2]), "v"(gx[q][3]), "v"(gx[q][4]), "v"(gx[q][5]),
+                         "v"(gx[q][6]), "v"(gx[q][7]));
+    };
+    auto g_finish = [&](int j) {
         const int c0 = tile_c0(j);
         const int vcol = c0 + 8 * gc;
         const bool masked = c0 != j * kBK;
         const unsigned gbuf = gbase + (j & 1) * kGBytes;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            float x[8];
-            grad8<DT>(raw[q], cf[q].m, cf[q].nl2, cf[q].sa, cf[q].syk, cf[q].sbk, cf[q].y - vcol, blank - vcol, masked,
-                      j * kBK - vcol, x);
-            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(x);
+            grad8_fix(cf[q].syk, cf[q].sbk, cf[q].y - vcol, blank - vcol, masked, j * kBK - vcol, gx[q]);
+            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(gx[q]);
         }
     };
     f32x16 acc[2][4];
@@ -264,26 +312,47 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
-    auto mma = [&](int j) {
-        const unsigned gbuf = gbase + (j & 1) * kGBytes;
-        mma_step<DT, 1>(lds0 + (j & 1) * kQBytes, boff, acc, [&](int s, int i) {
-            return *(const __attribute__((address_space(3))) frag *)(uintptr_t)(gbuf + aoff[s] + i * 32 * 128);
-        });
+    // (the per-step base addresses go through an empty asm: hipcc otherwise re-associates base + lane offset +
+    // constant into loop-invariant lane offset + constant registers and one vector add per LDS read)
+    auto opaque = [](unsigned v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto mma = [&](int j, const u32x4 (&raw)[2]) {  // tile j on the matrix cores, tile j + 1's gradient values beside it
+        const unsigned gbuf = gbase + (j & 1) * kGBytes, qbuf = lds0 + (j & 1) * kQBytes;
+        unsigned ga[4], bq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ga[k] = opaque(gbuf + aoff[k]);
+            bq[k] = opaque(qbuf + boff[k]);
+        }
+        mma_step<DT, 1>(
+            bq, acc,
+            [&](int s, int i) { return *(const __attribute__((address_space(3))) frag *)(uintptr_t)(ga[s] + i * 32 * 128); },
+            [&]() { g_main(raw); }, keep_gx);
     };
 
-    u32x4 raw[2];
+    // Step j: the logits of tile j + 2 and the weight rows of tile j + 1 are requested at its top and have the whole
+    // step to arrive; the wait in front of the barrier is the BUILTIN so that the compiler's own counter knows the
+    // loads have landed (it does not see the DMAs and would otherwise wait for them at the first use of `raw`).
+    u32x4 raw[2], raw_next[2];
     stage_q(0);
     load_tile(0, raw);
-    g_tile(0, raw);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    g_main(raw);
+    g_finish(0);
+    load_tile(1, raw);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    asm volatile("s_barrier" ::: "memory");
     for (int j = 0; j < NT; ++j) {
         const bool more = j + 1 < NT;
-        if (more) stage_q(j + 1);  // its buffer was last read in step j - 1, which every wave has left
-        load_tile(j + 1, raw);     // (past the last tile: offsets out of range, nothing is fetched)
-        mma(j);
-        if (more) g_tile(j + 1, raw);
-        // the DMAs of tile j + 1 have landed and this wave's gradient chunks are in LDS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        load_tile(j + 2, raw_next);  // (past the last tile: offsets out of range, nothing is fetched)
+        if (more) stage_q(j + 1);    // its buffer was last read in step j - 1, which every wave has left
+        mma(j, raw);                 // tile j on the matrix cores; the dense part of tile j + 1's gradient beside it
+        if (more) g_finish(j + 1);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) raw[q] = raw_next[q];
     }
 
     // ---- dH tile -> 16-bit, through LDS (the tile buffers are free: every wave is past the last barrier) so
@@ -367,14 +436,23 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
             const int rl = gr0 + 32 * q;
             long long cr = row0 + rl;
             cr = cr < coef_rows ? cr : coef_rows - 1;
+#ifndef FUSED_BWD_ABLATE_LOAD
             p.c0[q] = *reinterpret_cast<const float4 *>(&coefs[cr]);
             p.c1[q] = *(reinterpret_cast<const int4 *>(&coefs[cr]) + 1);
             p.raw[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((rl * V + vcol) * 2), 0, 0);
+#else
+            p.c0[q] = make_float4(0.f, 0.f, 1.f, 0.f);
+            p.c1[q] = make_int4(0, (int)cr, 1, 0);
+            p.raw[q] = u32x4{(unsigned)cr, 0u, 0u, 0u};
+            (void)rsrc;
+#endif
         }
     };
     float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this thread's share of the bias gradient
-    auto g_tile = [&](int j, const Pre &p) {
-        const unsigned gbuf = gbase + (j & 1) * kGBytes;
+    float gx[2][8];
+    float fsyk[2], fsbk[2];
+    int fdy[2];
+    auto g_main = [&](const Pre &p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             // padding nodes: zero coefficients (rnnt_bwd_node_coefs) and zero logits, whatever the tensor holds there
@@ -384,12 +462,26 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
             raw.y = ok ? raw.y : 0u;
             raw.z = ok ? raw.z : 0u;
             raw.w = ok ? raw.w : 0u;
-            float x[8];
-            grad8<DT>(raw, p.c0[q].x, p.c0[q].y, p.c0[q].z, p.c0[q].w, __int_as_float(p.c1[q].x), p.c1[q].y - vcol, db,
-                      masked, keep_from, x);
+            grad8_main<DT>(raw, p.c0[q].x, p.c0[q].y, p.c0[q].z, gx[q]);
+            fsyk[q] = p.c0[q].w;
+            fsbk[q] = __int_as_float(p.c1[q].x);
+            fdy[q] = p.c1[q].y - vcol;
+        }
+    };
+    auto keep_gx = [&]() {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[e] += x[e];
-            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(x);
+        for (int q = 0; q < 2; ++q)
+            asm volatile("" ::"v"(gx[q][0]), "v"(gx[q][1]), "v"(gx[q][2]), "v"(gx[q][3]), "v"(gx[q][4]), "v"(gx[q][5]),
+                         "v"(gx[q][6]), "v"(gx[q][7]));
+    };
+    auto g_finish = [&](int j) {
+        const unsigned gbuf = gbase + (j & 1) * kGBytes;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            grad8_fix(fsyk[q], fsbk[q], fdy[q], db, masked, keep_from, gx[q]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += gx[q][e];
+            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(gx[q]);
         }
     };
     auto stage_q = [&](int j) {  // hidden rows of step j -> Q buffer j & 1 (rows past the end: the last row, times g = 0)
@@ -399,7 +491,9 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
         for (int i = 0; i < kBK / kWaves; ++i) {
             const int kr = wave * (kBK / kWaves) + i;
             const long long row = row0 + kr < total_rows ? row0 + kr : total_rows - 1;
+#ifndef FUSED_BWD_ABLATE_DMA
             lds_dma16(dma_voff(lane, i & 3), reinterpret_cast<const char *>(hidden) + (size_t)row * kQRow, dst + kr * kQRow);
+#endif
         }
     };
 
@@ -420,25 +514,40 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
-    auto mma = [&](int j) {
-        const unsigned gbuf = gbase + (j & 1) * kGBytes;
-        mma_step<DT, 2>(lds0 + (j & 1) * kQBytes, boff, acc,
-                     [&](int s, int i) { return lds_read_tr_frag<frag>(gbuf + aoff[i] + s * 16 * 256, 4 * 256); });
+    auto opaque = [](unsigned v) {  // (see rnnt_fused_bwd_dh)
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto mma = [&](int j, const Pre &p) {
+        const unsigned gbuf = gbase + (j & 1) * kGBytes, qbuf = lds0 + (j & 1) * kQBytes;
+        unsigned ga[2], bq[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ga[k] = opaque(gbuf + aoff[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = opaque(qbuf + boff[k]);
+        mma_step<DT, 2>(
+            bq, acc, [&](int s, int i) { return lds_read_tr_frag<frag>(ga[i] + s * 16 * 256, 4 * 256); },
+            [&]() { g_main(p); }, keep_gx);
     };
 
-    if (nsteps > 0) {  // workgroup-uniform
-        Pre pre;
+    if (nsteps > 0) {  // workgroup-uniform; the pipeline of rnnt_fused_bwd_dh
+        Pre pre, pre_next;
         stage_q(0);
         load_step(0, pre);
-        g_tile(0, pre);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        g_main(pre);
+        g_finish(0);
+        load_step(1, pre);
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        asm volatile("s_barrier" ::: "memory");
         for (int j = 0; j < nsteps; ++j) {
             const bool more = j + 1 < nsteps;
+            load_step(j + 2, pre_next);
             if (more) stage_q(j + 1);
-            load_step(j + 1, pre);
-            mma(j);
-            if (more) g_tile(j + 1, pre);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            mma(j, pre);
+            if (more) g_finish(j + 1);
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            asm volatile("s_barrier" ::: "memory");
+            pre = pre_next;
         }
     }
 

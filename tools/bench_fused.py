@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only-backward", action="store_true", help="stage times of rnnt_joint_loss_backward only")
     args = ap.parse_args()
     import rnnt_amd
 
@@ -57,7 +58,11 @@ def main():
     ll = torch.full((B,), U, device=dev, dtype=torch.int32)
     crit = rnnt_amd.RNNTLoss(check_lengths=False)
     fused = rnnt_amd.FusedJointLoss(min_nodes=0)  # time the kernel itself, whatever the size
+    fused_r2 = rnnt_amd.FusedJointLoss(min_nodes=0, fused_backward=False)  # round 2: K3 + two library GEMMs
     go = torch.full((1,), 0.5, device=dev)
+
+    L = B * T * (U + 1)
+    flop = 2.0 * L * H * V
 
     def clear():
         hidden.grad = None
@@ -80,8 +85,54 @@ def main():
         clear()
         fused(hidden, proj, labels, al, ll).backward(go)
 
-    L = B * T * (U + 1)
-    flop = 2.0 * L * H * V
+    def fused_r2_step():
+        clear()
+        fused_r2(hidden, proj, labels, al, ll).backward(go)
+
+    def backward_stages():
+        """rnnt_joint_loss_backward alone, with the library's stage events: node coefficients, dH, dW + reduce."""
+        import ctypes
+        from rnnt_amd import _lib
+        from rnnt_amd.loss import _DTYPES
+        lib = _lib.load()
+        U1 = U + 1
+        with torch.no_grad():
+            logits = torch.empty(B, T, U1, V, dtype=dt, device=dev)
+            ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=dev)
+            costs = torch.empty(B, device=dev)
+            b32 = proj.bias.float().contiguous()
+            st = torch.cuda.current_stream().cuda_stream
+            opts = _lib.RnntOptions(st, 0, T, U1, _DTYPES[dt], None)
+            _lib.check(lib.rnnt_joint_loss_forward(hidden.data_ptr(), proj.weight.data_ptr(), b32.data_ptr(),
+                                                   logits.data_ptr(), labels.data_ptr(), al.data_ptr(), ll.data_ptr(),
+                                                   H, V, B, costs.data_ptr(), None, 0, ws.data_ptr(), opts), "fwd")
+            n = ctypes.c_size_t(0)
+            _lib.check(lib.rnnt_joint_loss_backward_workspace_size(H, V, B, T, U1, ctypes.byref(n)), "size")
+            bws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
+            dh, dw = torch.empty_like(hidden), torch.empty_like(proj.weight)
+            db = torch.empty(V, device=dev)
+            ev = _lib.StageEvents(4)
+            opts = _lib.RnntOptions(st, 0, T, U1, _DTYPES[dt], ev.ptr())
+            rows = []
+            for _ in range(args.reps + 3):
+                _lib.check(lib.rnnt_joint_loss_backward(hidden.data_ptr(), proj.weight.data_ptr(), logits.data_ptr(),
+                                                        labels.data_ptr(), al.data_ptr(), ll.data_ptr(), H, V, B,
+                                                        go.data_ptr(), 0, ctypes.c_float(1.0 / B), dh.data_ptr(),
+                                                        dw.data_ptr(), db.data_ptr(), ws.data_ptr(), bws.data_ptr(),
+                                                        opts), "bwd")
+                torch.cuda.synchronize()
+                rows.append([ev.elapsed_ms(i, i + 1) for i in range(3)])
+            rows = sorted(rows[3:], key=sum)
+            med = rows[len(rows) // 2]
+            ev.close()
+        return {"node_coefs": round(med[0], 4), "dH": round(med[1], 4), "dW+reduce": round(med[2], 4),
+                "dH_TFLOPs": round(flop / (med[1] * 1e-3) / 1e12, 1), "dW_TFLOPs": round(flop / (med[2] * 1e-3) / 1e12, 1),
+                "workspace_MB": round(int(n.value) / 1e6, 1)}
+
+    from rnnt_amd.fused import fused_backward_supported
+    if args.only_backward:
+        print(json.dumps({"shape": [B, T, U, V, H], "dtype": args.dtype, "fused_backward_stage_ms": backward_stages()}))
+        return
     res = {
         "shape": dict(B=B, T=T, U=U, V=V, H=H, nodes=L), "dtype": args.dtype, "device": torch.cuda.get_device_name(0),
         "gemm_flop": flop,
@@ -89,8 +140,11 @@ def main():
         "forward_ms": {"unfused (library GEMM + K1 + K2)": round(median_ms(unfused_fwd, args.reps), 4),
                        "fused (MFMA GEMM with K1 epilogue + K2)": round(median_ms(fused_fwd, args.reps), 4)},
         "forward_backward_ms": {"unfused": round(median_ms(unfused_step, args.reps), 4),
+                                "fused forward, K3 + two library GEMMs (round 2)": round(median_ms(fused_r2_step, args.reps), 4),
                                 "fused": round(median_ms(fused_step, args.reps), 4)},
     }
+    if fused_backward_supported(H, V):
+        res["fused_backward_stage_ms"] = backward_stages()
     f = res["forward_ms"]
     res["forward_speedup"] = round(f["unfused (library GEMM + K1 + K2)"] / f["fused (MFMA GEMM with K1 epilogue + K2)"], 3)
     res["forward_backward_speedup"] = round(res["forward_backward_ms"]["unfused"] / res["forward_backward_ms"]["fused"], 3)
