@@ -213,9 +213,10 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
  * range and added in range order: no atomics, results are bitwise reproducible.
  * workspace: the lattice workspace rnnt_joint_loss_forward / rnnt_forward filled.  backward_workspace: scratch of
  * rnnt_joint_loss_backward_workspace_size bytes, 256-byte aligned (node coefficients, partial sums of
- * grad_weight per node range).  hidden_size 512 (the reference's inner_dim), alphabet_size >= 128, 16-bit
- * options.dtype; hidden, weight, grad_hidden 16-byte and grad_weight 8-byte aligned.  INVALID_VALUE otherwise:
- * such callers run rnnt_backward and two library GEMMs (rnnt_amd/fused.py does).
+ * grad_weight per node range).  hidden_size 512 (the reference's inner_dim), alphabet_size >= 128 and a multiple
+ * of 8 (rows of the logits 16-byte aligned: they are fetched by LDS-DMA), 16-bit options.dtype; hidden, weight, logits,
+ * grad_hidden 16-byte and grad_weight 8-byte aligned.  INVALID_VALUE otherwise: such callers run rnnt_backward and
+ * two library GEMMs (rnnt_amd/fused.py does).
  * options.stage_events (optional): [0] start, [1] after the node coefficients, [2] after grad_hidden, [3] end.
  */
 rnntStatus_t rnnt_joint_loss_backward_workspace_size(int hidden_size, int alphabet_size, int minibatch, int maxT,

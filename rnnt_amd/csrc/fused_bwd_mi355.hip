@@ -52,22 +52,27 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * kWave;
 constexpr int kBM = 128;  // output rows per workgroup: lattice nodes (dH) or vocabulary entries (dW)
-constexpr int kBK = 64;   // contraction length per step: vocabulary entries (dH) or lattice nodes (dW)
+constexpr int kBK = 32;   // contraction length per step: vocabulary entries (dH) or lattice nodes (dW)
 constexpr int kH = 512;   // the projection's input size (the reference's inner_dim); N of both products
 constexpr int kQRow = kH * 2;          // bytes of one Q row = one LDS-DMA piece
-constexpr int kQBytes = kBK * kQRow;   // 64 KiB
-constexpr int kGBytes = kBM * kBK * 2; // 16 KiB
-constexpr int kLdsBytes = 2 * kQBytes + 2 * kGBytes;  // 160 KiB: all of a CU's LDS
-constexpr unsigned kOob = 0x80000000u;  // buffer offset past every range used here: the load returns 0, no request
+constexpr int kQBytes = kBK * kQRow;   // 32 KiB
+constexpr int kNQ = 3;                 // Q ring: the tile being multiplied, the next one (landed), one in flight
+constexpr int kGBytes = kBM * kBK * 2; // 8 KiB: one 1-KiB LDS-DMA piece per wave
+constexpr int kNG = 5;                 // gradient-tile ring: multiplied / converted in place / landed / two in flight
+constexpr int kCBytes = kWaves * 256;  // dW: node records of one step, 256 bytes per wave
+constexpr int kQ0 = 0, kG0 = kNQ * kQBytes, kC0 = kG0 + kNG * kGBytes;
+constexpr int kLdsBytesDh = kC0, kLdsBytesDw = kC0 + kNG * kCBytes;  // 136 KiB, 146 KiB
+constexpr int kDmaPerStep = kBK / kWaves;  // Q rows per wave and step
 
 // What K3 derives per lattice node (NodeCoef of lattice.h) in the form the tile prologue uses.
 struct __attribute__((aligned(32))) NodeG {
     float m, nl2, sa, syk;  // g_v = sa * 2^((x_v - m) log2e + nl2)  [- sbk at blank] [- syk at y]
     float sbk;
-    int y;                  // label of the node's emit arc, -1 if none
-    int valid;              // 0: padding (t >= T_b or u > U_b, or lengths that do not fit) -> g = 0 whatever the logits hold
-    int pad;
+    int y;                  // label of the node's emit arc, -1 if none, kPadding for a padding node (t >= T_b or
+                            // u > U_b, or lengths that do not fit): g = 0 there whatever the logits hold
+    int pad[2];
 };
+constexpr int kPadding = -2;
 
 __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ out, const int *__restrict__ labels,
                                                            const int *__restrict__ act_lens,
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ o
                                                            long long padded_rows) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= padded_rows) return;
-    NodeG g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, -1, 0, 0};
+    NodeG g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, kPadding, {0, 0}};
     if (r < total_rows) {
         const RowCoord c = decode_row(r, maxT, U1);
         const int Tb = act_lens[c.b];
@@ -93,7 +98,6 @@ __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ o
             g.syk = n.syk;
             g.sbk = n.sbk;
             g.y = n.y;
-            g.valid = 1;
         }
     }
     out[r] = g;
@@ -139,36 +143,76 @@ __device__ __forceinline__ unsigned dma_voff(int lane, int row_and_3) {
 typedef __attribute__((address_space(3))) u32x4 *lds_u128;
 typedef const __attribute__((address_space(3))) u32x4 *lds_cu128;
 
-// B fragments of one step for this wave's four 32-column tiles and the 32 MFMAs of the step.
-//   bq[jn]: this lane's LDS address inside the Q image for column tile jn, k-step 0, rows 8h + q
+// ---- pipeline of both MFMA kernels ----------------------------------------------------------------------------
+// Every global read inside the step loops is an LDS-DMA (inline asm, mma.h): no vector register is ever the
+// destination of a load in flight, so nothing the register allocator does (copies, live-range splits) can touch
+// data that has not landed, and the only wait counter to manage is the DMAs' own.  They retire in issue order
+// and every wave issues the same operations in the same order in every step, so "the N youngest may still be in
+// flight" is a compile-time constant.  Step j (kBK contraction elements, 16 MFMAs per wave):
+//   1. DMA of Q tile j + 2 into Q slot (j + 2) % 3 (last read in step j - 1, which every wave has left), then of the
+//      logits of tile j + 4 into gradient slot (j + 4) % 5 (last read in step j - 1) [dW: and its node records];
+//      issued one by one between the first MFMAs of 2.
+//   2. the MFMAs of tile j; between them the dense part of the conversion of tile j + 1: each thread reads the 16
+//      bytes of logits its own lane's DMA fetched (landed and behind a barrier since step j - 1) ...
+//   3. ... applies the corrections, rounds and writes the gradient values back IN PLACE
+//   4. s_waitcnt vmcnt(N): everything older than the N operations issued after the Q DMAs of step j - 1 has landed,
+//      i.e. Q tile j + 1 and the logits of tile j + 2; LDS writes done; barrier
+// N = L + (kDmaPerStep + L) with L = 1 (dH) or 2 (dW) DMAs after the Q pieces of a step.
+template <int L>
+struct Waits {
+    static constexpr int kStep = L + kDmaPerStep + L;
+};
+__device__ __forceinline__ void lds_dma4(unsigned voff, const void *sbase, unsigned lds_addr) {  // 4 bytes per lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
+// The 16 MFMAs of one step for this wave's 2 x 4 tiles of 32 x 32.
+//   bq[jn]: this lane's LDS address inside the Q tile for column tile jn, k-step 0, rows 8h + q
 //   AFRAG(s, i): A fragment of k-step s, row tile i (differs between the two kernels)
 //   A_READS: LDS read instructions per A fragment (1: ds_read_b128, 2: transposed)
-// The fragments of k-step s + 1 are read between the MFMAs of k-step s; the order is pinned with
-// sched_group_barrier (left alone, hipcc hoists every read of the step to its top and spills the accumulators).
+// The fragments of k-step 1 are read between the MFMAs of k-step 0; the order is pinned with sched_group_barrier
+// (left alone, hipcc hoists every read to the top and spills the accumulators).
 //   VALU: vector-ALU work that does not depend on this step (the dense part of the next tile's gradient values):
-//         three of its instructions go between consecutive MFMAs, where the matrix pipe leaves the issue port idle
-template <typename DT, int A_READS, typename AFRAG, typename VALU, typename KEEP>
-__device__ __forceinline__ void mma_step(const unsigned (&bq)[4], f32x16 (&acc)[2][4], AFRAG afrag, VALU valu, KEEP keep) {
+//         a few of its instructions go between consecutive MFMAs, where the matrix pipe leaves the issue port idle
+//   BETWEEN(k), k = 0 .. 5: called after the k-th fragment read of k-step 1, i.e. between the MFMAs of k-step 0: the
+//         step's LDS-DMAs go there one by one (an asm statement with a "memory" clobber stays between the LDS reads
+//         around it).  Issued back to back at the top of the step they cost the wave 100-180 cycles each with
+//         nothing else of its own to overlap; beside its MFMAs the issue is hidden.
+template <typename DT, int A_READS, typename AFRAG, typename VALU, typename KEEP, typename BETWEEN>
+__device__ __forceinline__ void mma_step(const unsigned (&bq)[4], f32x16 (&acc)[2][4], AFRAG afrag, VALU valu, KEEP keep,
+                                         BETWEEN between) {
     typedef typename Mma<DT>::frag frag;
     constexpr int KS = kBK / 16;
     frag a[2][2], b[2][4];  // [k-step parity]
     auto read_frags = [&](int s) {
 #ifndef FUSED_BWD_ABLATE_READ
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[s & 1][i] = afrag(s, i);
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+        for (int jn = 0; jn < 4; ++jn) {
             b[s & 1][jn] = lds_read_tr_frag<frag>(bq[jn] + s * 16 * kQRow, 4 * kQRow);
+            if (s == 1) between(jn);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[s & 1][i] = afrag(s, i);
+            if (s == 1) between(4 + i);
+        }
 #else
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[s & 1][i] = __builtin_bit_cast(frag, u32x4{bq[0], bq[1], bq[2], (unsigned)(s + i)});
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) b[s & 1][jn] = __builtin_bit_cast(frag, u32x4{bq[jn], bq[1], bq[2], (unsigned)s});
+        if (s == 1)
+            for (int k = 0; k < 6; ++k) between(k);
 #endif
     };
     __builtin_amdgcn_sched_barrier(0);
     read_frags(0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * A_READS + 8, 0);
+    static_assert(kBK / 16 == 2, "the DMAs are placed in k-step 0");
     valu();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -183,13 +227,14 @@ __device__ __forceinline__ void mma_step(const unsigned (&bq)[4], f32x16 (&acc)[
                 asm volatile("" ::"v"(a[s & 1][i]), "v"(b[s & 1][jn]));
 #endif
             }
-        // 8 MFMAs with the next k-step's 2 A_READS + 8 reads spread between them: 2,1,x,1,2,1,x,1 (x = A_READS)
+        // 8 MFMAs with the next k-step's 8 + 2 A_READS reads spread between them, in program order (four B fragments
+        // of two reads each, then two A fragments of A_READS each): 2,1,1,2,1,1,x,x
 #define MMA1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0)
 #define DSR(N) __builtin_amdgcn_sched_group_barrier(0x100, N, 0)
 #define VAL __builtin_amdgcn_sched_group_barrier(0x002, FUSED_BWD_VALU_PER_MFMA, 0)
         if (s + 1 < KS) {
-            MMA1; DSR(2); VAL; MMA1; DSR(1); VAL; MMA1; DSR(A_READS); VAL; MMA1; DSR(1); VAL;
-            MMA1; DSR(2); VAL; MMA1; DSR(1); VAL; MMA1; DSR(A_READS); VAL; MMA1; DSR(1); VAL;
+            MMA1; DSR(2); VAL; MMA1; DSR(1); VAL; MMA1; DSR(1); VAL; MMA1; DSR(2); VAL;
+            MMA1; DSR(1); VAL; MMA1; DSR(1); VAL; MMA1; DSR(A_READS); VAL; MMA1; DSR(A_READS); VAL;
         } else {
             MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL; MMA1; VAL;
         }
@@ -202,6 +247,13 @@ __device__ __forceinline__ void mma_step(const unsigned (&bq)[4], f32x16 (&acc)[
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// (per-step LDS base addresses go through an empty asm: hipcc otherwise re-associates base + lane offset +
+// constant into loop-invariant lane offset + constant registers and one vector add per LDS read)
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // dH[node, :] = sum_v g[node, v] W[v, :]
 // ---------------------------------------------------------------------------------------------------------
@@ -212,9 +264,9 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
                        long long total_rows) {
     typedef typename DT::elem E;
     typedef typename Mma<DT>::frag frag;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes];
+    typedef Waits<1> W;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytesDh];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned gbase = lds0 + 2 * kQBytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -226,34 +278,35 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     const int NT = (V + kBK - 1) / kBK;
     auto tile_c0 = [&](int j) { return min(j * kBK, V - kBK); };  // the last tile overlaps its predecessor
 
-    // ---- the gradient tile's producer side: thread -> chunk gc of rows gr0 and gr0 + 64 ----
-    const int gc = tid & 7, gr0 = tid >> 3;
-    NodeG cf[2];
-    unsigned row_off[2], gw[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int rl = gr0 + 64 * q;
-        const long long row = wg_row0 + rl < total_rows ? wg_row0 + rl : total_rows - 1;
+    // ---- producer side.  Gradient tile in LDS: [128 nodes][32 v], 64-byte rows, 16-byte chunk c of node n at
+    // position c ^ ((n >> 2) & 3).  Thread tid owns the 16 bytes at tid * 16, in every step: its lane's DMA fetches
+    // the logits there, the thread converts them in place.  That is node gr, chunk gc:
+    const int gr = tid >> 2;
+    const int gc = (tid & 3) ^ ((gr >> 2) & 3);
+    float cm, cnl2, csa, csyk, csbk;
+    int cy;
+    bool ok;
+    {
+        const long long row = wg_row0 + gr < total_rows ? wg_row0 + gr : total_rows - 1;
         const float4 c0 = *reinterpret_cast<const float4 *>(&coefs[row]);
-        const int4 c1 = *(reinterpret_cast<const int4 *>(&coefs[row]) + 1);
-        const bool ok = rl < wg_rows && c1.z != 0;
-        cf[q].m = ok ? c0.x : 0.0f;
-        cf[q].nl2 = ok ? c0.y : 0.0f;
-        cf[q].sa = ok ? c0.z : 0.0f;
-        cf[q].syk = ok ? c0.w : 0.0f;
-        cf[q].sbk = ok ? __int_as_float(c1.x) : 0.0f;
-        cf[q].y = ok ? c1.y : -1;
-        row_off[q] = ok ? (unsigned)((rl * V + 8 * gc) * 2) : kOob;  // padding nodes load nothing and read zeros
-        // LDS image [128 nodes][64 v]: 128-byte rows, 16-byte chunk c of row n at chunk c ^ ((n >> 1) & 7)
-        gw[q] = (unsigned)(rl * 128 + ((gc ^ ((rl >> 1) & 7)) << 4));
+        const int2 c1 = *(reinterpret_cast<const int2 *>(&coefs[row]) + 2);
+        ok = gr < wg_rows && c1.y != kPadding;
+        cm = ok ? c0.x : 0.0f;
+        cnl2 = ok ? c0.y : 0.0f;
+        csa = ok ? c0.z : 0.0f;
+        csyk = ok ? c0.w : 0.0f;
+        csbk = ok ? __int_as_float(c1.x) : 0.0f;
+        cy = ok ? c1.y : -1;
     }
-    const __amdgpu_buffer_rsrc_t rows_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<E *>(logits) + (size_t)wg_row0 * V, (short)0, (int)((size_t)wg_rows * V * 2), 0x00020000);
+    // (rows past the end of the tensor: the last row's logits are fetched and ignored)
+    const unsigned l_voff = (unsigned)(((gr < wg_rows ? gr : wg_rows - 1) * V + 8 * gc) * 2);
+    const char *l_base = reinterpret_cast<const char *>(logits + (size_t)wg_row0 * V);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // the node record has landed: no compiler-visible load is in flight below
 
     // ---- consumer side ----
-    unsigned aoff[4], boff[4];
+    unsigned aoff[2], boff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) aoff[s] = (unsigned)((64 * wm + r) * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) << 4));
+    for (int s = 0; s < 2; ++s) aoff[s] = (unsigned)((64 * wm + r) * 64 + (((2 * s + h) ^ ((r >> 2) & 3)) << 4));
     {
         const int q4 = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
@@ -261,49 +314,39 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
             boff[jn] = (unsigned)((8 * h + q4) * kQRow + (((4 * wn + jn) ^ q4) << 6) + 32 * g1 + 8 * p);
     }
 
-    auto stage_q = [&](int j) {  // weight rows tile_c0(j) .. +63 -> Q buffer j & 1, eight rows per wave
-        const char *src = reinterpret_cast<const char *>(weight) + (size_t)tile_c0(j) * kQRow;
-        const unsigned dst = lds0 + (j & 1) * kQBytes;
-#pragma unroll
-        for (int i = 0; i < kBK / kWaves; ++i) {
-            const int kr = wave * (kBK / kWaves) + i;
+    // step j's DMAs, k = 0 .. 3: weight row k of this wave's four of Q tile j + 2; k = 4: logits of tile j + 4
+    auto issue = [&](int j, int k) {
+        if (k < kDmaPerStep) {
+            const int t = j + 2 < NT ? j + 2 : NT - 1;  // (past the end: the last tile again; never read)
+            const int kr = wave * kDmaPerStep + k;
+            const char *src = reinterpret_cast<const char *>(weight) + ((size_t)tile_c0(t) + kr) * kQRow;
 #ifndef FUSED_BWD_ABLATE_DMA
-            lds_dma16(dma_voff(lane, i & 3), src + (size_t)kr * kQRow, dst + kr * kQRow);
+            if (j + 2 >= 0) lds_dma16(dma_voff(lane, k & 3), src, lds0 + kQ0 + ((j + 2) % kNQ) * kQBytes + kr * kQRow);
 #endif
-        }
-    };
-    auto load_tile = [&](int j, u32x4 (&raw)[2]) {
-        const unsigned off = j < NT ? (unsigned)(tile_c0(j) * 2) : kOob;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        } else if (k == kDmaPerStep) {
+            const int t = j + 4 < NT ? j + 4 : NT - 1;
 #ifndef FUSED_BWD_ABLATE_LOAD
-            raw[q] = __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc, row_off[q] + off, 0, 0);
-#else
-            raw[q] = u32x4{off, row_off[q], 0u, 0u};
+            lds_dma16(l_voff, l_base + (size_t)tile_c0(t) * 2, lds0 + kG0 + ((j + 4) % kNG) * kGBytes + wave * 1024);
 #endif
         }
     };
-    float gx[2][8];  // the gradient values of the next tile, before the corrections
-    auto g_main = [&](const u32x4 (&raw)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) grad8_main<DT>(raw[q], cf[q].m, cf[q].nl2, cf[q].sa, gx[q]);
-    };
+    float gx[8];  // the gradient values of the next tile, before the corrections
     auto keep_gx = [&]() {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            asm volatile("" ::"v"(gx[q][0]), "v"(gx[q][1]), "v"(gx[q][2]), "v"(gx[q][3]), "v"(gx[q][4]), "v"(gx[q][5]),
-                         "v"(gx[q][6]), "v"(gx[q][7]));
+        asm volatile("" ::"v"(gx[0]), "v"(gx[1]), "v"(gx[2]), "v"(gx[3]), "v"(gx[4]), "v"(gx[5]), "v"(gx[6]), "v"(gx[7]));
     };
-    auto g_finish = [&](int j) {
+    auto conv_main = [&](int j) {
+        u32x4 raw = *(lds_cu128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16);
+        raw.x = ok ? raw.x : 0u;  // padding nodes: g = 0 whatever the logits hold
+        raw.y = ok ? raw.y : 0u;
+        raw.z = ok ? raw.z : 0u;
+        raw.w = ok ? raw.w : 0u;
+        grad8_main<DT>(raw, cm, cnl2, csa, gx);
+    };
+    auto conv_finish = [&](int j) {
         const int c0 = tile_c0(j);
         const int vcol = c0 + 8 * gc;
-        const bool masked = c0 != j * kBK;
-        const unsigned gbuf = gbase + (j & 1) * kGBytes;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            grad8_fix(cf[q].syk, cf[q].sbk, cf[q].y - vcol, blank - vcol, masked, j * kBK - vcol, gx[q]);
-            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(gx[q]);
-        }
+        grad8_fix(csyk, csbk, cy - vcol, blank - vcol, c0 != j * kBK, j * kBK - vcol, gx);
+        *(lds_u128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16) = DT::pack(gx);
     };
     f32x16 acc[2][4];
 #pragma unroll
@@ -312,52 +355,38 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
-    // (the per-step base addresses go through an empty asm: hipcc otherwise re-associates base + lane offset +
-    // constant into loop-invariant lane offset + constant registers and one vector add per LDS read)
-    auto opaque = [](unsigned v) {
-        asm volatile("" : "+v"(v));
-        return v;
-    };
-    auto mma = [&](int j, const u32x4 (&raw)[2]) {  // tile j on the matrix cores, tile j + 1's gradient values beside it
-        const unsigned gbuf = gbase + (j & 1) * kGBytes, qbuf = lds0 + (j & 1) * kQBytes;
-        unsigned ga[4], bq[4];
+    auto mma = [&](int j) {  // tile j on the matrix cores, tile j + 1's gradient values beside it
+        const unsigned gbuf = lds0 + kG0 + (j % kNG) * kGBytes, qbuf = lds0 + kQ0 + (j % kNQ) * kQBytes;
+        unsigned ga[2], bq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ga[k] = opaque(gbuf + aoff[k]);
-            bq[k] = opaque(qbuf + boff[k]);
-        }
+        for (int k = 0; k < 2; ++k) ga[k] = opaque(gbuf + aoff[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = opaque(qbuf + boff[k]);
         mma_step<DT, 1>(
             bq, acc,
-            [&](int s, int i) { return *(const __attribute__((address_space(3))) frag *)(uintptr_t)(ga[s] + i * 32 * 128); },
-            [&]() { g_main(raw); }, keep_gx);
+            [&](int s, int i) { return *(const __attribute__((address_space(3))) frag *)(uintptr_t)(ga[s] + i * 32 * 64); },
+            [&]() { conv_main(j + 1); }, keep_gx, [&](int k) { issue(j, k); });
     };
 
-    // Step j: the logits of tile j + 2 and the weight rows of tile j + 1 are requested at its top and have the whole
-    // step to arrive; the wait in front of the barrier is the BUILTIN so that the compiler's own counter knows the
-    // loads have landed (it does not see the DMAs and would otherwise wait for them at the first use of `raw`).
-    u32x4 raw[2], raw_next[2];
-    stage_q(0);
-    load_tile(0, raw);
-    g_main(raw);
-    g_finish(0);
-    load_tile(1, raw);
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    asm volatile("s_barrier" ::: "memory");
-    for (int j = 0; j < NT; ++j) {
-        const bool more = j + 1 < NT;
-        load_tile(j + 2, raw_next);  // (past the last tile: offsets out of range, nothing is fetched)
-        if (more) stage_q(j + 1);    // its buffer was last read in step j - 1, which every wave has left
-        mma(j, raw);                 // tile j on the matrix cores; the dense part of tile j + 1's gradient beside it
-        if (more) g_finish(j + 1);
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        asm volatile("s_barrier" ::: "memory");
+    // ---- prologue: the DMAs of steps -4 .. -1, everything landed, tile 0 converted ----
+    for (int j = -4; j < 0; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) raw[q] = raw_next[q];
-    }
+        for (int k = 0; k <= kDmaPerStep; ++k) issue(j, k);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    conv_main(0);
+    conv_finish(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // ---- dH tile -> 16-bit, through LDS (the tile buffers are free: every wave is past the last barrier) so
-    // that rows leave as whole 16-byte pieces ----
+    for (int j = 0; j < NT; ++j) {
+        mma(j);  // (and the DMAs of step j)
+        if (j + 1 < NT) conv_finish(j + 1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W::kStep) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // nothing may land in LDS once it is reused below
+
+    // ---- dH tile -> 16-bit, through LDS so that rows leave as whole 16-byte pieces ----
     constexpr int SP = kQRow + 16;  // staging pitch
+    static_assert(kBM * SP <= kLdsBytesDh, "staging tile");
     typedef __attribute__((address_space(3))) E *lds_elem;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -388,11 +417,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ hidden,
                        const NodeG *__restrict__ coefs, float *__restrict__ partial, float *__restrict__ pbias, int V,
                        int blank, long long total_rows, long long coef_rows, int nvb, int steps_per_chunk) {
-    typedef typename DT::elem E;
     typedef typename Mma<DT>::frag frag;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes];
+    typedef Waits<2> W;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytesDw];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned gbase = lds0 + 2 * kQBytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -408,93 +436,79 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     const long long rows_here = total_rows - row_begin;
     const int nsteps = rows_here <= 0 ? 0 : (int)min((long long)steps_per_chunk, (rows_here + kBK - 1) / kBK);
 
-    // ---- producer side: thread -> chunk gc (eight vocabulary entries) of nodes gr0 and gr0 + 32 of the step ----
-    const int gc = tid & 15, gr0 = tid >> 4;
+    // ---- producer side.  Gradient tile in LDS: [32 nodes][128 v], 256-byte rows, 64-byte window w of node n at
+    // window w ^ (n & 3).  Thread tid owns the 16 bytes at tid * 16 (DMA destination of its lane, converted in
+    // place): node gr of the step, chunk gc (eight vocabulary entries from vcol).
+    const int gr = tid >> 4;
+    const int gc = ((((tid >> 2) & 3) ^ (gr & 3)) << 2) | (tid & 3);
     const int vcol = vb0 + 8 * gc;
     const int db = blank - vcol, keep_from = vmin - vcol;
-    unsigned gw[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int rl = gr0 + 32 * q;
-        // LDS image [64 nodes][128 v]: 256-byte rows, 64-byte window w of row n at window w ^ (n & 3)
-        gw[q] = (unsigned)(rl * 256 + ((((gc >> 2) ^ (rl & 3)) << 6) | ((gc & 3) << 4)));
-    }
-    struct Pre {  // what the prologue of one step needs, loaded a step ahead
-        u32x4 raw[2];
-        float4 c0[2];
-        int4 c1[2];
-    };
-    auto load_step = [&](int j, Pre &p) {
-        const long long row0 = row_begin + (long long)j * kBK;
-        long long left = total_rows - row0;
-        left = j < nsteps ? (left < kBK ? left : kBK) : 0;  // rows of this step that exist; none: every load returns 0
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<E *>(logits) + (size_t)(j < nsteps ? row0 : 0) * V, (short)0, (int)((size_t)left * V * 2),
-            0x00020000);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int rl = gr0 + 32 * q;
-            long long cr = row0 + rl;
-            cr = cr < coef_rows ? cr : coef_rows - 1;
+
+    // step j's DMAs, k = 0 .. 3: hidden row k of this wave's four of step j + 2; k = 4: logits, k = 5: node records of
+    // step j + 4
+    auto issue = [&](int j, int k) {
+        if (k < kDmaPerStep) {
+            if (j + 2 >= 0) {
+                const long long row0 = row_begin + (long long)(j + 2 < nsteps ? j + 2 : 0) * kBK;
+                const int kr = wave * kDmaPerStep + k;
+                const long long row = row0 + kr < total_rows ? row0 + kr : total_rows - 1;  // (times g = 0)
+#ifndef FUSED_BWD_ABLATE_DMA
+                lds_dma16(dma_voff(lane, k & 3), reinterpret_cast<const char *>(hidden) + (size_t)row * kQRow,
+                          lds0 + kQ0 + ((j + 2) % kNQ) * kQBytes + kr * kQRow);
+#endif
+            }
+        } else {
+            const long long row0 = row_begin + (long long)(j + 4 < nsteps ? j + 4 : 0) * kBK;
+            const unsigned slot = (unsigned)((j + 4) % kNG);
 #ifndef FUSED_BWD_ABLATE_LOAD
-            p.c0[q] = *reinterpret_cast<const float4 *>(&coefs[cr]);
-            p.c1[q] = *(reinterpret_cast<const int4 *>(&coefs[cr]) + 1);
-            p.raw[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((rl * V + vcol) * 2), 0, 0);
-#else
-            p.c0[q] = make_float4(0.f, 0.f, 1.f, 0.f);
-            p.c1[q] = make_int4(0, (int)cr, 1, 0);
-            p.raw[q] = u32x4{(unsigned)cr, 0u, 0u, 0u};
-            (void)rsrc;
+            if (k == kDmaPerStep) {
+                // logits: this wave's piece = nodes 4 wave .. 4 wave + 3 of the step (past the end: the last node, ignored)
+                long long lrow = row0 + gr;
+                lrow = lrow < total_rows ? lrow : total_rows - 1;
+                const long long wrow0 = row0 + 4 * wave < total_rows ? row0 + 4 * wave : total_rows - 1;  // wave-uniform
+                const unsigned voff = (unsigned)(((lrow - wrow0) * V + vcol) * 2);  // 0 .. 3 rows on, this lane's chunk
+                lds_dma16(voff, reinterpret_cast<const char *>(logits) + (size_t)wrow0 * V * 2,
+                          lds0 + kG0 + slot * kGBytes + wave * 1024);
+            } else {
+                // node records of the same four nodes: 128 bytes, fetched by lanes 0-31 (and again by lanes 32-63)
+                long long crow0 = row0 + 4 * wave;
+                crow0 = crow0 + 4 <= coef_rows ? crow0 : coef_rows - 4;
+                lds_dma4((unsigned)((lane & 31) * 4), reinterpret_cast<const char *>(coefs + crow0),
+                         lds0 + kC0 + slot * kCBytes + wave * 256);
+            }
 #endif
         }
     };
     float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this thread's share of the bias gradient
-    float gx[2][8];
-    float fsyk[2], fsbk[2];
-    int fdy[2];
-    auto g_main = [&](const Pre &p) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            // padding nodes: zero coefficients (rnnt_bwd_node_coefs) and zero logits, whatever the tensor holds there
-            const bool ok = p.c1[q].z != 0;
-            u32x4 raw = p.raw[q];
-            raw.x = ok ? raw.x : 0u;
-            raw.y = ok ? raw.y : 0u;
-            raw.z = ok ? raw.z : 0u;
-            raw.w = ok ? raw.w : 0u;
-            grad8_main<DT>(raw, p.c0[q].x, p.c0[q].y, p.c0[q].z, gx[q]);
-            fsyk[q] = p.c0[q].w;
-            fsbk[q] = __int_as_float(p.c1[q].x);
-            fdy[q] = p.c1[q].y - vcol;
-        }
+    float gx[8];
+    float fsyk, fsbk;
+    int fdy;
+    auto conv_main = [&](int j) {
+        const unsigned slot = (unsigned)(j % kNG);
+        const unsigned ca = lds0 + kC0 + slot * kCBytes + wave * 256 + (lane >> 4) * 32;
+        const u32x4 c0 = *(lds_cu128)(uintptr_t)ca;
+        const u32x2 c1 = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)(ca + 16);
+        u32x4 raw = *(lds_cu128)(uintptr_t)(lds0 + kG0 + slot * kGBytes + tid * 16);
+        // padding nodes: zero coefficients (rnnt_bwd_node_coefs) and zero logits, whatever the tensor holds there
+        const bool ok = (int)c1.y != kPadding;
+        raw.x = ok ? raw.x : 0u;
+        raw.y = ok ? raw.y : 0u;
+        raw.z = ok ? raw.z : 0u;
+        raw.w = ok ? raw.w : 0u;
+        grad8_main<DT>(raw, __uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), gx);
+        fsyk = __uint_as_float(c0.w);
+        fsbk = __uint_as_float(c1.x);
+        fdy = (int)c1.y - vcol;
     };
     auto keep_gx = [&]() {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            asm volatile("" ::"v"(gx[q][0]), "v"(gx[q][1]), "v"(gx[q][2]), "v"(gx[q][3]), "v"(gx[q][4]), "v"(gx[q][5]),
-                         "v"(gx[q][6]), "v"(gx[q][7]));
+        asm volatile("" ::"v"(gx[0]), "v"(gx[1]), "v"(gx[2]), "v"(gx[3]), "v"(gx[4]), "v"(gx[5]), "v"(gx[6]), "v"(gx[7]),
+                     "v"(fsyk), "v"(fsbk), "v"(fdy));
     };
-    auto g_finish = [&](int j) {
-        const unsigned gbuf = gbase + (j & 1) * kGBytes;
+    auto conv_finish = [&](int j) {
+        grad8_fix(fsyk, fsbk, fdy, db, masked, keep_from, gx);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            grad8_fix(fsyk[q], fsbk[q], fdy[q], db, masked, keep_from, gx[q]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[e] += gx[q][e];
-            *(lds_u128)(uintptr_t)(gbuf + gw[q]) = DT::pack(gx[q]);
-        }
-    };
-    auto stage_q = [&](int j) {  // hidden rows of step j -> Q buffer j & 1 (rows past the end: the last row, times g = 0)
-        const long long row0 = row_begin + (long long)j * kBK;
-        const unsigned dst = lds0 + (j & 1) * kQBytes;
-#pragma unroll
-        for (int i = 0; i < kBK / kWaves; ++i) {
-            const int kr = wave * (kBK / kWaves) + i;
-            const long long row = row0 + kr < total_rows ? row0 + kr : total_rows - 1;
-#ifndef FUSED_BWD_ABLATE_DMA
-            lds_dma16(dma_voff(lane, i & 3), reinterpret_cast<const char *>(hidden) + (size_t)row * kQRow, dst + kr * kQRow);
-#endif
-        }
+        for (int e = 0; e < 8; ++e) bsum[e] += gx[e];
+        *(lds_u128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16) = DT::pack(gx);
     };
 
     // ---- consumer side: A = g^T (vocabulary entry on the lane, nodes in the registers: transposed reads) ----
@@ -514,12 +528,8 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.0f;
-    auto opaque = [](unsigned v) {  // (see rnnt_fused_bwd_dh)
-        asm volatile("" : "+v"(v));
-        return v;
-    };
-    auto mma = [&](int j, const Pre &p) {
-        const unsigned gbuf = gbase + (j & 1) * kGBytes, qbuf = lds0 + (j & 1) * kQBytes;
+    auto mma = [&](int j) {
+        const unsigned gbuf = lds0 + kG0 + (j % kNG) * kGBytes, qbuf = lds0 + kQ0 + (j % kNQ) * kQBytes;
         unsigned ga[2], bq[4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) ga[k] = opaque(gbuf + aoff[k]);
@@ -527,28 +537,23 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
         for (int k = 0; k < 4; ++k) bq[k] = opaque(qbuf + boff[k]);
         mma_step<DT, 2>(
             bq, acc, [&](int s, int i) { return lds_read_tr_frag<frag>(ga[i] + s * 16 * 256, 4 * 256); },
-            [&]() { g_main(p); }, keep_gx);
+            [&]() { conv_main(j + 1); }, keep_gx, [&](int k) { issue(j, k); });
     };
 
     if (nsteps > 0) {  // workgroup-uniform; the pipeline of rnnt_fused_bwd_dh
-        Pre pre, pre_next;
-        stage_q(0);
-        load_step(0, pre);
-        g_main(pre);
-        g_finish(0);
-        load_step(1, pre);
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-        asm volatile("s_barrier" ::: "memory");
+        for (int j = -4; j < 0; ++j)
+#pragma unroll
+            for (int k = 0; k <= kDmaPerStep + 1; ++k) issue(j, k);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        conv_main(0);
+        conv_finish(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int j = 0; j < nsteps; ++j) {
-            const bool more = j + 1 < nsteps;
-            load_step(j + 2, pre_next);
-            if (more) stage_q(j + 1);
-            mma(j, pre);
-            if (more) g_finish(j + 1);
-            __builtin_amdgcn_s_waitcnt(0x0070);
-            asm volatile("s_barrier" ::: "memory");
-            pre = pre_next;
+            mma(j);  // (and the DMAs of step j)
+            if (j + 1 < nsteps) conv_finish(j + 1);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W::kStep) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
     // ---- partial products out: fp32, [rc][vb][128 v][512]; register e of a tile is one row of 32 consecutive floats ----
@@ -567,7 +572,7 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     float *bl = reinterpret_cast<float *>(smem);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bl[gr0 * kBM + 8 * gc + e] = bsum[e];
+    for (int e = 0; e < 8; ++e) bl[gr * kBM + 8 * gc + e] = bsum[e];
     __syncthreads();
     if (tid < kBM) {
         float s = 0.0f;
@@ -683,7 +688,7 @@ extern "C" {
 
 rnntStatus_t rnnt_joint_loss_backward_workspace_size(int hidden_size, int alphabet_size, int minibatch, int maxT,
                                                      int maxU, size_t *size_bytes) {
-    if (!size_bytes || hidden_size != kH || alphabet_size < kBM || minibatch <= 0 || maxT <= 0 || maxU <= 0)
+    if (!size_bytes || hidden_size != kH || alphabet_size < kBM || alphabet_size % 8 != 0 || minibatch <= 0 || maxT <= 0 || maxU <= 0)
         return RNNT_STATUS_INVALID_VALUE;
     const DwPlan p = dw_plan((long long)minibatch * maxT * maxU, alphabet_size);
     *size_bytes = carve_bwd(nullptr, p).bytes;
@@ -698,14 +703,14 @@ rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, co
     if (!hidden || !weight || !logits || !act_lens || !label_lens || !workspace || !backward_workspace)
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
-    if (hidden_size != kH || alphabet_size < kBM) return RNNT_STATUS_INVALID_VALUE;
+    if (hidden_size != kH || alphabet_size < kBM || alphabet_size % 8 != 0) return RNNT_STATUS_INVALID_VALUE;
     if (minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.maxU > RNNT_MAX_LATTICE_COLUMNS)
         return RNNT_STATUS_INVALID_VALUE;
     if (options.blank_label < 0 || options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     if (options.dtype != RNNT_DTYPE_BF16 && options.dtype != RNNT_DTYPE_F16) return RNNT_STATUS_INVALID_VALUE;
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0 || reinterpret_cast<uintptr_t>(backward_workspace) % 256 != 0 ||
         reinterpret_cast<uintptr_t>(hidden) % 16 != 0 || reinterpret_cast<uintptr_t>(weight) % 16 != 0 ||
-        reinterpret_cast<uintptr_t>(logits) % 2 != 0 || reinterpret_cast<uintptr_t>(grad_hidden) % 16 != 0 ||
+        reinterpret_cast<uintptr_t>(logits) % 16 != 0 || reinterpret_cast<uintptr_t>(grad_hidden) % 16 != 0 ||
         reinterpret_cast<uintptr_t>(grad_weight) % 8 != 0 || reinterpret_cast<uintptr_t>(grad_bias) % 4 != 0)
         return RNNT_STATUS_INVALID_VALUE;
     if ((size_t)kBM * alphabet_size * 2 > 0x7fffffffu) return RNNT_STATUS_INVALID_VALUE;  // one buffer range per row tile

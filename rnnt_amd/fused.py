@@ -30,7 +30,7 @@ DEFAULT_MIN_NODES = 16384
 
 def fused_backward_supported(H: int, V: int) -> bool:
     """Shapes ``rnnt_joint_loss_backward`` takes (include/rnnt_mi355.h); others run K3 + two library GEMMs."""
-    return H == 512 and V >= 128
+    return H == 512 and V >= 128 and V % 8 == 0
 
 
 class _FusedJointLossFunction(torch.autograd.Function):
