@@ -131,6 +131,10 @@ rnntStatus_t compute_rnnt_loss(const void *acts, void *grads, const int *labels,
  * array: calls that overlap on one GPU (two streams, two threads) race; serialise them.  Nothing needs
  * clearing between calls (every value read is written earlier in the same call).  Same kernels, same
  * results bit for bit as compute_rnnt_loss.
+ * Under HIP graph capture: make ONE call per device BEFORE capture begins (the first call on a device looks the
+ * array's address up with hipGetDevice + hipGetSymbolAddress, a synchronous runtime call that may load the code
+ * object and is not capturable); later calls only enqueue kernels.  Every replay of a captured graph uses the same
+ * per-GPU array: replays of graphs that contain this call must not overlap on one GPU either.
  */
 #define RNNT_STATIC_WORKSPACE_BYTES (32u << 20) /* 32 MiB: config 2 (B32 T400 U40) needs 21.7 MB */
 rnntStatus_t compute_rnnt_loss_static(const void *acts, void *grads, const int *labels,

@@ -9,11 +9,13 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RNNT_AMD_LIB: developer override to A/B differently-built libraries (tools/sweep.sh)
-LIB_PATH = os.environ.get("RNNT_AMD_LIB") or os.path.join(_HERE, "lib", "librnnt_mi355.so")
+# (No environment override: the product loads its own in-tree library and nothing else.  Developer A/B runs of
+# differently-built libraries go through tools/with_lib.py, which sets LIB_PATH before anything is loaded.)
+LIB_PATH = os.path.join(_HERE, "lib", "librnnt_mi355.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 ABI_VERSION = 1
 
@@ -74,7 +76,8 @@ _lib = None
 def build(verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", CSRC_DIR], stdout=out)
+    # PYTHON: the compiled binding must be built against the torch of the interpreter that will load it
+    subprocess.check_call(["make", "-C", CSRC_DIR, "PYTHON=" + sys.executable], stdout=out)
     return LIB_PATH
 
 

@@ -43,7 +43,7 @@ def load():
             torch.ops.load_library(TORCH_LIB_PATH)
             ops = torch.ops.rnnt_amd
             mapped = _mapped_kernel_libraries()
-            if len(mapped) > 1:  # e.g. an RNNT_AMD_LIB override built without -Wl,-soname,librnnt_mi355.so
+            if len(mapped) > 1:  # e.g. a tools/with_lib.py library built without -Wl,-soname,librnnt_mi355.so
                 raise _lib.RnntLibraryError(
                     "two copies of the kernels library are mapped (" + ", ".join(sorted(mapped)) + "): the compiled "
                     "binding would run one and the ctypes entry points the other; build the override with "

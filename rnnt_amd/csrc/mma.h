@@ -47,6 +47,15 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const void *sbase, unsi
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory");
 }
+// the same for bytes that this CU reads once and no other does: streaming ("nt") policy, they do not displace
+// what the other CUs of the XCD keep re-reading from its L2
+__device__ __forceinline__ void lds_dma16_nt(unsigned voff, const void *sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
 
 // Two ds_read_b64_tr_b16 = one 32x32x16 fragment whose k index is the ROW index of a row-major LDS image:
 // within a group of 16 lanes, lane 4q + p passes the address of row q, columns 4p .. 4p+3 of a 4 x 16 block and

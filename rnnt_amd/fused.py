@@ -134,6 +134,9 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
     if hidden.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError("fused_joint_loss takes bfloat16 or float16 activations (fp32: use JointNet + RNNTLoss; "
                         "the fp32 matrix rate of the MI355X is 1/16 of the 16-bit one)")
+    if bias is None:
+        raise ValueError("fused_joint_loss needs the projection's bias (nn.Linear(bias=True)); pass a zero vector for a "
+                         "projection without one")
     if weight.dtype is not hidden.dtype:
         raise TypeError("weight must have hidden's dtype")
     if hidden.dim() != 4 or weight.dim() != 2 or bias.dim() != 1:
@@ -171,7 +174,8 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
     if B * T * U1 < min_nodes:
         from .loss import rnnt_loss
 
-        logits = torch.nn.functional.linear(hidden, weight, bias.to(hidden.dtype))
+        # as the kernel: fp32 accumulation, the bias added in fp32 (whatever its dtype), one rounding to the 16-bit type
+        logits = torch.nn.functional.linear(hidden.float(), weight.float(), bias.float()).to(hidden.dtype)
         return rnnt_loss(logits, labels, act_lens, label_lens, blank=blank, reduction=reduction, check_lengths=False)
     return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction,
                                          fused_backward)

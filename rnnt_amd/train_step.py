@@ -103,7 +103,9 @@ class GuardedStep:
         group = None if self.group is True else self.group
         full = [g if g is not None else torch.zeros_like(p) for p, g in zip(self.params, grads)]
         out = list(full)
-        for dtype in {g.dtype for g in full}:
+        # (first-occurrence order of the parameters: a set of dtypes iterates in an order that may differ between
+        # the rank processes, and the ranks must issue their collectives in the same order)
+        for dtype in dict.fromkeys(g.dtype for g in full):
             idx = [i for i, g in enumerate(full) if g.dtype == dtype]
             flat = torch.cat([full[i].reshape(-1) for i in idx])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -185,3 +185,18 @@ def test_compiled_torch_binding_loads_without_a_gpu():
     one = torch.ones(1, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.rnnt_loss(a, lab, one, one, 0, 1)
+
+
+def test_default_import_ignores_library_override_in_the_environment():
+    """The product loads its own in-tree library and nothing else: RNNT_AMD_LIB (a developer switch until round 2)
+    is not read; differently-built libraries go through tools/with_lib.py."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os; from rnnt_amd import _lib; "
+            "assert _lib.LIB_PATH == os.path.join(os.path.dirname(_lib.__file__), 'lib', 'librnnt_mi355.so'), _lib.LIB_PATH")
+    env = dict(os.environ, RNNT_AMD_LIB="/nonexistent/librnnt_mi355.so")
+    subprocess.check_call([sys.executable, "-c", code], cwd=root, env=env)
+    src = open(os.path.join(root, "rnnt_amd", "_lib.py")).read()
+    assert "os.environ" not in src

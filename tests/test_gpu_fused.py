@@ -193,12 +193,27 @@ def test_small_lattices_take_the_unfused_composition():
         outs.append((loss.detach(), h.grad, w.grad, b.grad))
     assert 2 * 20 * 5 < rnnt_amd.fused.DEFAULT_MIN_NODES
     h, w, b = (x.to(DEV).requires_grad_(True) for x in (hidden, weight, bias))
-    ref = rnnt_amd.RNNTLoss(check_lengths=False)(torch.nn.functional.linear(h, w, b), lab, ald, lld)
+    # (the composition as the kernel forms it: fp32 accumulation, fp32 bias, one rounding to the 16-bit type)
+    ref = rnnt_amd.RNNTLoss(check_lengths=False)(
+        torch.nn.functional.linear(h.float(), w.float(), b.float()).to(h.dtype), lab, ald, lld)
     ref.backward()
     assert torch.equal(outs[0][0], ref.detach()) and torch.equal(outs[0][1], h.grad) and torch.equal(outs[0][2], w.grad)
     assert abs(float(outs[0][0]) - float(outs[1][0])) <= 2e-4 * abs(float(outs[1][0]))
     for a, c in zip(outs[0][1:], outs[1][1:]):
         assert float((a.float() - c.float()).abs().max()) <= 4 * EPS[torch.bfloat16] * float(c.float().abs().max()) + 1e-6
+
+
+def test_fp32_bias_gives_the_same_logits_on_both_sides_of_min_nodes():
+    """An fp32 bias parameter is added in fp32 by the kernel and by the small-lattice composition alike: the two
+    paths see the same logits (loss within fp32 summation order), not logits that differ by the bias's rounding."""
+    import rnnt_amd
+
+    hidden, weight, bias, labels, al, ll = make_inputs(2, 20, 4, 300, 256, torch.bfloat16, seed=23)
+    bias32 = (bias.float() * 3.0 + 0.001234)        # not representable in bf16
+    lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
+    a = rnnt_amd.fused_joint_loss(hidden.to(DEV), weight.to(DEV), bias32.to(DEV), lab, ald, lld, min_nodes=0)
+    b = rnnt_amd.fused_joint_loss(hidden.to(DEV), weight.to(DEV), bias32.to(DEV), lab, ald, lld, min_nodes=10 ** 9)
+    assert abs(float(a) - float(b)) <= 2e-4 * abs(float(a))   # (logits on a rounding boundary may differ by one step)
 
 
 class _Proj:
@@ -239,6 +254,8 @@ def test_fused_argument_checks():
         rnnt_amd.fused_joint_loss(h.float(), w.float(), b.float(), lab, ald, lld)
     with pytest.raises(ValueError, match="inner sizes"):
         rnnt_amd.fused_joint_loss(h[..., :320].contiguous(), w[:, :320].contiguous(), b, lab, ald, lld)
+    with pytest.raises(ValueError, match="needs the projection's bias"):
+        rnnt_amd.fused_joint_loss(h, w, None, lab, ald, lld)
     with pytest.raises(ValueError, match="at least 64"):
         rnnt_amd.fused_joint_loss(h, w[:40].contiguous(), b[:40].contiguous(), lab, ald, lld)
     with pytest.raises(RuntimeError, match="no CPU path"):

@@ -140,16 +140,19 @@ def test_balanced_partition_equals_unsharded_bitwise(tmp_path):
 class TinyTransducer(torch.nn.Module):
     """enc/dec features -> logits [B,T,U+1,V] the way the reference's joint does (model.py:39-59)."""
 
-    def __init__(self, D=6, V=7):
+    def __init__(self, D=6, V=7, mixed=False):
         super().__init__()
         torch.manual_seed(3)
         self.enc = torch.nn.Linear(D, 8)
+        if mixed:   # parameters of two dtypes: GuardedStep all-reduces per dtype, in the same order on every rank
+            self.enc = self.enc.double()
         self.dec = torch.nn.Embedding(V, 8)
         self.out = torch.nn.Linear(8, V)
         self.unused = torch.nn.Parameter(torch.zeros(2))  # never reached by the loss: .grad stays None
 
     def forward(self, feats, tokens_with_bos):
-        h = torch.tanh(self.enc(feats).unsqueeze(2) + self.dec(tokens_with_bos).unsqueeze(1))
+        e = self.enc(feats.to(self.enc.weight.dtype)).float()
+        h = torch.tanh(e.unsqueeze(2) + self.dec(tokens_with_bos).unsqueeze(1))
         return self.out(h)
 
 
@@ -173,7 +176,7 @@ def _train(model, batches, world, rank, mode):
 
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     guard = GuardedStep(model.parameters(), accumulation_steps=1, max_grad_norm=5.0,
-                        group=True if mode == "guarded" else None)
+                        group=True if mode.startswith("guarded") else None)
     for feats, labels, al, ll in batches:
         B = feats.shape[0]
         full = [torch.from_numpy(x) for x in (feats, labels, al, ll)]
@@ -202,21 +205,22 @@ def training_worker(rank, world, port, mode, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        params = _train(TinyTransducer(), _training_batches(5, 3), world, rank, mode)
+        params = _train(TinyTransducer(mixed=mode.endswith("mixed")), _training_batches(5, 3), world, rank, mode)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), **params)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["helper", "guarded"])
+@pytest.mark.parametrize("mode", ["helper", "guarded", "guarded-mixed"])
 def test_two_ranks_train_like_one(tmp_path, mode):
     """sharded loss + SUM all-reduce of the parameter gradients reproduces the
     unsharded training run (what DataParallel's reduce-add gave the reference), including a skipped
     NaN batch and gradient clipping; both ranks end with the same parameters."""
     world = 2
     mp.spawn(training_worker, args=(world, free_port(), mode, str(tmp_path)), nprocs=world, join=True)
-    ref = _train(TinyTransducer(), _training_batches(5, 3), 1, 0, "single")
-    start = {k: v.detach().numpy() for k, v in TinyTransducer().state_dict().items()}
+    mixed = mode.endswith("mixed")
+    ref = _train(TinyTransducer(mixed=mixed), _training_batches(5, 3), 1, 0, "single")
+    start = {k: v.detach().numpy() for k, v in TinyTransducer(mixed=mixed).state_dict().items()}
     assert any(np.abs(ref[k] - start[k]).max() > 1e-3 for k in ref)      # training moved the parameters
     r0, r1 = (np.load(tmp_path / f"r{r}.npz") for r in range(world))
     for k in ref:

@@ -81,3 +81,39 @@ def test_static_workspace_checks_against_the_oracle_and_refuses_what_does_not_fi
     # ... and the same minibatch is fine through the allocating entry point
     s, c, g = _call(lib, "compute_rnnt_loss", big, lab, tal, tll, _lib.DTYPE_F32, True)
     assert s == 0 and np.isfinite(c).all()
+
+
+def test_static_entry_point_under_graph_capture_after_a_warm_up_call():
+    """The use the header names: one call per device BEFORE capture (the first call looks the device array up, which
+    is not capturable), then the call is captured into a HIP graph and replayed on new inputs; the replays allocate
+    nothing and equal compute_rnnt_loss bit for bit."""
+    from rnnt_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, T, U, V = 3, 29, 6, 515
+    a, l, al, ll = make_case(B, T, U, V, seed=21, ragged=True)
+    acts = torch.from_numpy(a).to(dev)
+    tl, tal, tll = (torch.from_numpy(x).to(dev) for x in (l, al, ll))
+    grads = torch.empty_like(acts)
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+
+    def enqueue():
+        opts = _lib.RnntOptions(torch.cuda.current_stream(dev).cuda_stream, 0, T, U + 1, _lib.DTYPE_F32, None)
+        return lib.compute_rnnt_loss_static(acts.data_ptr(), grads.data_ptr(), tl.data_ptr(), tll.data_ptr(),
+                                            tal.data_ptr(), V, B, costs.data_ptr(), opts)
+
+    assert enqueue() == 0                      # warm-up: the per-device lookup happens here
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert enqueue() == 0
+    for seed in (22, 23):
+        a2, _, _, _ = make_case(B, T, U, V, seed=seed, ragged=True)
+        acts.copy_(torch.from_numpy(a2))
+        grads.fill_(float("nan"))
+        costs.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        s, c, g = _call(lib, "compute_rnnt_loss", acts, tl, tal, tll, _lib.DTYPE_F32, True)
+        assert s == 0 and np.array_equal(costs.cpu().numpy(), c) and np.array_equal(grads.cpu().numpy(), g)
