@@ -175,6 +175,28 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
 
+    # which device each rank really drives: the scaling numbers only mean something if the N ranks sit on N
+    # distinct GPUs, so every rank reports (rank, device index, uuid, PCI address) and rank 0 prints the table
+    props = torch.cuda.get_device_properties(dev)
+    me = {
+        "rank": rank,
+        "local_rank": local_rank,
+        "device": torch.cuda.current_device(),
+        "uuid": str(getattr(props, "uuid", "")),
+        "pci": "{:04x}:{:02x}:{:02x}".format(getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                             getattr(props, "pci_device_id", 0)),
+        "name": props.name,
+        "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")),
+    }
+    if sharded:
+        rccl_ranks = [None] * world
+        dist.all_gather_object(rccl_ranks, me)
+    else:
+        rccl_ranks = [me]
+    distinct_devices = len({(r["uuid"], r["pci"]) for r in rccl_ranks})
+    if sharded and distinct_devices != world:
+        raise SystemExit(f"{world} ranks share {distinct_devices} device(s): {rccl_ranks}")
+
     if args.workload == "custom":
         f = (args.shape or "").split(",")
         if len(f) < 5:
@@ -188,7 +210,7 @@ def main():
     go = torch.full((1,), 0.5, dtype=torch.float32, device=dev)  # grad_output != 1 exercises the fused scale
 
     if sharded:
-        crit = rnnt_amd.ShardedRNNTLoss(blank=0, reduction="mean")
+        crit = rnnt_amd.ShardedRNNTLoss(blank=0, reduction="mean", check_lengths=not args.no_check_lengths)
 
         def step():
             acts.grad = None
@@ -296,6 +318,8 @@ def main():
             "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         },
         "loss": loss_val,
+        "rccl_ranks": rccl_ranks,
+        "distinct_devices": distinct_devices,
     }
     # HBM bytes per K3 launch from the PMC counters cannot be collected inside this process: they come from the
     # committed rocprofv3 passes over this same command (tools/profile.sh), and only for the workload they ran.

@@ -475,11 +475,17 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     const bool emit = valid && c.u < Ub;
     const int y = emit ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
     const bool y_ok = y >= 0 && y < V;
-    // lanes 0-31 fetch the blank logit, lanes 32-63 the label logit of the same node; loads that bypass
-    // the CU's vector cache: a neighbouring wave may have pulled a line shared with this row into it
-    // before this wave's last stores landed
+    // lanes 0-31 fetch the blank logit, lanes 32-63 the label logit of the same node, with AGENT-SCOPE loads
+    // (global_load_ushort ... sc1): they are served by the XCD's L2, where this wave's own stores have arrived (the
+    // s_waitcnt vmcnt(0) above: the vector L1 is write-through), never by a line of the CU's L1 that a neighbouring
+    // wave pulled in before those stores landed.  (Picking the two values out of the accumulators / the transpose
+    // buffer in the epilogue of the tile that holds them was built in round 3: the label and the picked pair stay
+    // live across the vocabulary walk, and at the 256-register limit of this kernel that cost 23-30 spilled VGPRs
+    // with scratch reloads inside the walk; a load per node at the end costs nothing there.)
     const int pick = h == 0 ? blank : (y_ok ? y : 0);
-    const float xg = DT::to_float(__builtin_nontemporal_load(out_row + pick));
+    const unsigned short xbits = __hip_atomic_load(reinterpret_cast<const unsigned short *>(out_row) + pick,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float xg = DT::to_float(__builtin_bit_cast(E, xbits));
     const float x_other = __shfl_xor(xg, 32, kWave);
     if (valid && h == 0) {
         const float logs = row_log_sum(S, M);

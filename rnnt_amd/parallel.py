@@ -111,10 +111,13 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None,
                 off += p.numel()
 
 
-def _default_loss_fn(acts, labels, act_lens, label_lens, blank):
-    from .loss import rnnt_loss
+def _default_loss_fn(check_lengths: bool):
+    def loss_fn(acts, labels, act_lens, label_lens, blank):
+        from .loss import rnnt_loss
 
-    return rnnt_loss(acts, labels, act_lens, label_lens, blank=blank, reduction="none")
+        return rnnt_loss(acts, labels, act_lens, label_lens, blank=blank, reduction="none", check_lengths=check_lengths)
+
+    return loss_fn
 
 
 def ordered_reduce(costs: torch.Tensor, reduction: str) -> torch.Tensor:
@@ -150,17 +153,23 @@ class ShardedRNNTLoss(torch.nn.Module):
         loss_fn: ``f(acts, labels, act_lens, label_lens, blank) -> [B_local] costs`` with autograd.
             Defaults to the HIP kernels.  The CPU (gloo) tests inject the oracle here; the
             product default never touches a CPU implementation.
+        check_lengths: upstream's host-side length check (``rnnt_amd.rnnt_loss``) in the default ``loss_fn``.
+            Off by default here: it costs one host wait per step and rank, and a shard of a ragged batch rarely has
+            ``T == max(act_lens)`` anyway (out-of-range lengths still give a NaN cost, never a fault).
+
+    Nothing in ``forward`` waits on the host: the all-reduce of the per-utterance costs is launched asynchronously
+    right behind K2 and waited for (on the stream, for RCCL) only where the scalar is formed.
     """
 
     def __init__(self, blank: int = 0, reduction: str = "mean", group=None,
-                 loss_fn: Optional[Callable] = None):
+                 loss_fn: Optional[Callable] = None, check_lengths: bool = False):
         super().__init__()
         if reduction not in ("none", "mean", "sum"):
             raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
         self.blank = blank
         self.reduction = reduction
         self.group = group
-        self.loss_fn = loss_fn or _default_loss_fn
+        self.loss_fn = loss_fn or _default_loss_fn(check_lengths)
 
     def forward(self, acts, labels, act_lens, label_lens, global_batch: Optional[int] = None,
                 offset: Optional[int] = None, index: Optional[Sequence[int]] = None):
@@ -203,11 +212,13 @@ class ShardedRNNTLoss(torch.nn.Module):
         # the one collective: per-utterance costs, 4*B_global bytes, latency-bound
         gathered = torch.zeros(global_batch, dtype=torch.float32, device=local.device)
         if where is not None:
-            where = where.to(local.device)
+            where = where.to(local.device, non_blocking=True)
             gathered[where] = local.detach()
         else:
             gathered[offset:offset + b_local] = local.detach()
-        dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group)
+        work = dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        local_sum = local.sum() if self.reduction != "none" else None   # (independent of the collective)
+        work.wait()  # RCCL: the compute stream waits for the collective's stream; the host does not block
 
         if self.reduction == "none":
             out = gathered.clone()
@@ -219,5 +230,4 @@ class ShardedRNNTLoss(torch.nn.Module):
         factor = 1.0 / global_batch if self.reduction == "mean" else 1.0
         value = ordered_reduce(gathered, self.reduction)
         # value of the global loss, gradient only through this rank's utterances
-        local_sum = local.sum()
         return value + (local_sum - local_sum.detach()) * factor

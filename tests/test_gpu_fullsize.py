@@ -3,6 +3,8 @@ would take minutes there): rows of the gradient sum to zero, per-node logit shif
 padding is exactly zero and its content (NaN) is ignored, batch permutation commutes, repeated
 runs are bitwise identical (no atomics anywhere), alpha/beta agree on the likelihood, and a
 sampled utterance matches the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,6 +320,57 @@ def test_config5_full_size():
         del sub
 
 
+@pytest.mark.parametrize("B,V", [(16, 64), (64, 16)])
+def test_config5_lattice_mean_reduction_gradient_bar(B, V):
+    """reduction='mean' — the reference's only mode (model.py:87) — at config 5's lattice (T=1500, U=150; a small
+    vocabulary so that the CPU oracle can hold the gradients), against the fp32 CPU oracle AND float64.
+
+    The bar as DESIGN.md §4 states it:  |g - g_cpu32| <= max(1e-4, 8 ulp32(max|ll|) |grad_output| / B).
+    |ll| ~ 6e3 here, so one fp32 ulp of alpha + beta - ll is 4.9e-4; the recurrences of both fp32 implementations
+    accumulate a few of those over the 1650 anti-diagonals (the fp32 oracle itself sits that far from float64), and
+    the 1/B of 'mean' scales the result.  B = 64: the bound is 6e-5 and the north-star's 1e-4 is asserted strictly.
+    B = 16 (config 5's batch): the bound is 2.4e-4; measured 1.2e-4 against the fp32 oracle, i.e. the strict 1e-4
+    is NOT met there — and cannot be by any fp32 implementation that is not the oracle's own rounding sequence, since
+    the oracle is further than that from float64.  What is asserted instead: the stated bound, and that the GPU is no
+    further from float64 than twice the fp32 oracle's own distance.  Every measured figure goes to
+    gpurun_out/relaxed_grad_parity.jsonl (committed per round under profiles/)."""
+    import json
+
+    from cases import RELAXED_LOG, make_case
+
+    T, U = 1500, 150
+    acts, labels, al, ll = make_case(B, T, U, V, seed=1516, ragged=True)
+    al[0], ll[0] = T, U
+    c, g, _ = oracle.rnnt_loss_c(acts, labels, al, ll)
+    ref_loss, ref_g = oracle.reduce_like_upstream(c, g, "mean", 1.0)
+    del g
+    _, g64, _ = oracle.rnnt_loss_c(acts, labels, al, ll, dtype=np.float64)
+    g64 /= B
+    loss, gm = run(torch.from_numpy(acts).to(DEV), labels, al, ll, reduction="mean", go=1.0)
+    gm = gm.cpu().numpy()
+    ref_loss = float(np.asarray(ref_loss).ravel()[0])
+    assert abs(float(loss.reshape(-1)[0]) - ref_loss) <= 1e-5 * abs(ref_loss)
+    max_ll = float(np.abs(c).max())
+    assert max_ll > 4096                                                   # the regime the statement is about
+    ulp = float(np.spacing(np.float32(max_ll)))
+    bound = max(1e-4, 8.0 * ulp * 1.0 / B)
+    err = float(np.abs(gm - ref_g).max())
+    e_gpu, e_cpu = float(np.abs(gm - g64).max()), float(np.abs(ref_g - g64).max())
+    try:
+        os.makedirs(os.path.dirname(RELAXED_LOG), exist_ok=True)
+        with open(RELAXED_LOG, "a") as f:
+            f.write(json.dumps({"case": f"T1500 U150 V{V} B{B} mean", "reduction": "mean", "shape": list(gm.shape),
+                                "max_abs_ll": max_ll, "ulp32_of_ll": ulp, "stated_bound": bound,
+                                "max_abs_dg_vs_f32_oracle": err, "gpu_vs_f64": e_gpu, "f32_oracle_vs_f64": e_cpu,
+                                "strict_1e-4_met": err <= 1e-4}) + "\n")
+    except OSError:
+        pass
+    assert err <= bound, (err, bound)
+    assert e_gpu <= max(2 * e_cpu, 1e-4), (e_gpu, e_cpu)
+    if B == 64:
+        assert bound == 1e-4 and err <= 1e-4
+
+
 def test_config5_lattice_shape_small_vocab_with_gradients():
     """T=1500, U=150 (config 5's lattice: 1650 anti-diagonals, three K2 waves per direction with the LDS
     edge hand-off) at a vocabulary small enough for the oracle to produce gradients: costs and gradients
@@ -335,11 +388,9 @@ def test_config5_lattice_shape_small_vocab_with_gradients():
     np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5)
     assert_grad_parity(gn.cpu().numpy(), g, g64, reduction="none", label="T1500 U150 V256 unscaled")
     # |ll| is ~9e3 here, one fp32 ulp of alpha+beta-ll is 1e-3: the fp32 CPU oracle itself sits 8e-3 from
-    # float64 on the few nodes every path crosses (profiles/r02_relaxed_grad_parity.jsonl), so 1e-4 absolute
-    # is below what fp32 resolves on this lattice, for the reference's CPU path as for this one; the check
-    # above is the float64-anchored one.  'mean' is the same gradient times grad_output / B, exactly:
-    loss, gm = run(a, labels, al, ll, reduction="mean", go=1.0)
-    assert abs(float(loss) - float(np.float32(c.sum(dtype=np.float32) / 2))) <= 1e-5 * abs(float(loss))
-    assert float((gm - gn * 0.5).abs().max()) <= 1e-7
+    # float64 on the few nodes every path crosses (profiles/r03_relaxed_grad_parity.jsonl), so 1e-4 absolute
+    # is below what fp32 resolves on this lattice FOR UNSCALED GRADIENTS, for the reference's CPU path as for this
+    # one; the check above is the float64-anchored one.  The bar itself: 1e-4 absolute holds while
+    # 8 ulp(|ll|) * |grad_output| / B <= 1e-4 — see the 'mean' test above, which measures both sides of that line.
     ca, ll_alpha, beta00 = lattice_planes(a, labels, al, ll)
     np.testing.assert_allclose(beta00, ll_alpha, rtol=1e-5)

@@ -31,12 +31,27 @@ def test_single_rank_rccl_equals_unsharded_bitwise():
             a1 = d(acts).requires_grad_(True)
             a2 = d(acts).requires_grad_(True)
             l1 = rnnt_amd.RNNTLoss(reduction=reduction)(a1, d(labels), d(al), d(ll))
-            l2 = rnnt_amd.ShardedRNNTLoss(reduction=reduction)(a2, d(labels), d(al), d(ll), global_batch=5)
             go = torch.full_like(l1, 0.5)
             l1.backward(go)
-            l2.backward(go)
+            args = (a2, d(labels), d(al), d(ll))
+            # the sharded default waits for nothing on the host: no length check (check_lengths=False), the
+            # all-reduce asynchronous behind K2, the ordered reduction on the device
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                l2 = rnnt_amd.ShardedRNNTLoss(reduction=reduction)(*args, global_batch=5)
+                l2.backward(go)
+                if reduction == "mean":  # a non-contiguous partition, too (its index table goes up without a wait)
+                    l5 = rnnt_amd.ShardedRNNTLoss(reduction=reduction)(
+                        args[0].detach(), *args[1:], global_batch=5, index=[0, 1, 2, 3, 4])
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            if reduction == "mean":
+                assert torch.equal(l5, l2.detach())
             assert torch.equal(l1, l2), reduction
             assert torch.equal(a1.grad, a2.grad), reduction
+        # check_lengths=True brings the host-side check back (one host wait): a length beyond T raises
+        with pytest.raises(ValueError, match="Input length mismatch"):
+            rnnt_amd.ShardedRNNTLoss(check_lengths=True)(d(acts), d(labels), d(al) + 1, d(ll), global_batch=5)
         # a shard in the middle of a larger global batch: gradient scaled by 1/B_global
         a3 = d(acts).requires_grad_(True)
         l3 = rnnt_amd.ShardedRNNTLoss(reduction="mean")(a3, d(labels), d(al), d(ll), global_batch=5)
