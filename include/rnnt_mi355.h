@@ -199,6 +199,19 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
                                      const int *label_lens, int hidden_size, int alphabet_size,
                                      int minibatch, float *costs, float *loss_out, int reduction,
                                      void *workspace, rnntOptions options);
+/*
+ * The same with padded rows: row r of logits_out starts logits_row_stride (>= alphabet_size) elements after row
+ * r-1; the elements alphabet_size .. logits_row_stride-1 of a row are never touched.  A stride that is a multiple
+ * of 64 elements puts every row on a 128-byte line: the kernel's 16-byte stores then never straddle two 64-byte
+ * request blocks (V = 4232, bf16: 2.71 -> 2.35 ms for the forward at B32 T400 U40, profiles/r03_tuning.md).
+ * rnnt_backward wants contiguous rows; rnnt_joint_loss_backward_strided takes the padded tensor.
+ * (rnnt_joint_loss_forward is this call with logits_row_stride = alphabet_size.)
+ */
+rnntStatus_t rnnt_joint_loss_forward_strided(const void *hidden, const void *weight, const float *bias,
+                                             void *logits_out, int logits_row_stride, const int *labels,
+                                             const int *act_lens, const int *label_lens, int hidden_size,
+                                             int alphabet_size, int minibatch, float *costs, float *loss_out,
+                                             int reduction, void *workspace, rnntOptions options);
 
 /*
  * Backward of the pair above with K3 as the PROLOGUE of the projection's two backward products: replaces what
@@ -217,8 +230,9 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
  * range and added in range order: no atomics, results are bitwise reproducible.
  * workspace: the lattice workspace rnnt_joint_loss_forward / rnnt_forward filled.  backward_workspace: scratch of
  * rnnt_joint_loss_backward_workspace_size bytes, 256-byte aligned (node coefficients, partial sums of
- * grad_weight per node range).  hidden_size 512 (the reference's inner_dim), alphabet_size >= 128 and a multiple
- * of 8 (rows of the logits 16-byte aligned: they are fetched by LDS-DMA), 16-bit options.dtype; hidden, weight, logits,
+ * grad_weight per node range; the size does not depend on the logits' row stride).  hidden_size 512 (the reference's
+ * inner_dim), alphabet_size >= 128 and, for this contiguous call, a multiple of 8 (rows of the logits 16-byte
+ * aligned: they are fetched by LDS-DMA; see the strided call below), 16-bit options.dtype; hidden, weight, logits,
  * grad_hidden 16-byte and grad_weight 8-byte aligned.  INVALID_VALUE otherwise: such callers run rnnt_backward and
  * two library GEMMs (rnnt_amd/fused.py does).
  * options.stage_events (optional): [0] start, [1] after the node coefficients, [2] after grad_hidden, [3] end.
@@ -230,6 +244,19 @@ rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, co
                                       int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
                                       float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
                                       const void *workspace, void *backward_workspace, rnntOptions options);
+/*
+ * The same on logits with padded rows (logits_out of rnnt_joint_loss_forward_strided): logits_row_stride a multiple
+ * of 8 elements.  With logits_row_stride >= alphabet_size rounded up to a multiple of 128 ANY alphabet_size >= 128 is
+ * taken (the reference's 4234 and 5455 too): the kernels then read whole tiles, on into the padding, and mask the
+ * entries from alphabet_size on (whatever the padding holds, NaN included).  With a smaller stride alphabet_size
+ * must be a multiple of 8, as for the contiguous call (which is this call with logits_row_stride = alphabet_size).
+ */
+rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *weight, const void *logits,
+                                              int logits_row_stride, const int *labels, const int *act_lens,
+                                              const int *label_lens, int hidden_size, int alphabet_size, int minibatch,
+                                              const float *grad_out, int grad_out_stride, float grad_scale,
+                                              void *grad_hidden, void *grad_weight, float *grad_bias,
+                                              const void *workspace, void *backward_workspace, rnntOptions options);
 
 /*
  * ---- greedy decoding --------------------------------------------------------

@@ -38,8 +38,10 @@ EXPORTED_SYMBOLS = (
     "compute_rnnt_loss_static",
     "rnnt_reduce_costs",
     "rnnt_joint_loss_forward",
+    "rnnt_joint_loss_forward_strided",
     "rnnt_joint_loss_backward_workspace_size",
     "rnnt_joint_loss_backward",
+    "rnnt_joint_loss_backward_strided",
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
@@ -124,11 +126,18 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_loss_forward.argtypes = [vp, vp, fp, vp, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 fp, fp, ctypes.c_int, vp, RnntOptions]
         lib.rnnt_joint_loss_forward.restype = ctypes.c_int
+        lib.rnnt_joint_loss_forward_strided.argtypes = [vp, vp, fp, vp, ctypes.c_int, ip, ip, ip, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, fp, fp, ctypes.c_int, vp, RnntOptions]
+        lib.rnnt_joint_loss_forward_strided.restype = ctypes.c_int
         lib.rnnt_joint_loss_backward_workspace_size.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)]
         lib.rnnt_joint_loss_backward_workspace_size.restype = ctypes.c_int
         lib.rnnt_joint_loss_backward.argtypes = [vp, vp, vp, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  fp, ctypes.c_int, ctypes.c_float, vp, vp, fp, vp, vp, RnntOptions]
         lib.rnnt_joint_loss_backward.restype = ctypes.c_int
+        lib.rnnt_joint_loss_backward_strided.argtypes = [vp, vp, vp, ctypes.c_int, ip, ip, ip, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int, fp, ctypes.c_int, ctypes.c_float, vp, vp, fp, vp, vp,
+                                                         RnntOptions]
+        lib.rnnt_joint_loss_backward_strided.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_joint_hidden_forward.restype = ctypes.c_int

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ o
 // order — so that the rounded tile equals what rnnt_backward would have written.  In two parts: the dense part
 // (branch-free: it is scheduled between the MFMAs of the previous tile) and the corrections.  dy / db: position of
 // the label / blank logit relative to this chunk's first element; the corrections are real branches (one lane in
-// hundreds takes them); `keep_from`: elements below it belong to the previous, overlapping tile and give 0.
+// hundreds takes them); of a `masked` chunk only elements keep_from <= j < keep_until count, the others give 0:
+// those below belong to the previous, overlapping tile (rows without padding), those above lie past the vocabulary,
+// in the padding of a row whose stride is a multiple of 128 (EdgeMode below).
 template <typename DT>
 __device__ __forceinline__ void grad8_main(const u32x4 &raw, float m, float nl2, float sa, float (&x)[8]) {
     DT::unpack(raw, x);
@@ -117,7 +119,8 @@ __device__ __forceinline__ void grad8_main(const u32x4 &raw, float m, float nl2,
     for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j] - m, kLog2e, nl2)) * sa;
 #endif
 }
-__device__ __forceinline__ void grad8_fix(float syk, float sbk, int dy, int db, bool masked, int keep_from, float (&x)[8]) {
+__device__ __forceinline__ void grad8_fix(float syk, float sbk, int dy, int db, bool masked, int keep_from, int keep_until,
+                                          float (&x)[8]) {
     if ((unsigned)db < 8u) {
         asm volatile("; blank-logit correction" ::: "memory");  // keeps this a branch (see grad_chunk)
 #pragma unroll
@@ -130,7 +133,7 @@ __device__ __forceinline__ void grad8_fix(float syk, float sbk, int dy, int db, 
     }
     if (masked) {  // workgroup-uniform
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (j >= keep_from) ? x[j] : 0.0f;
+        for (int j = 0; j < 8; ++j) x[j] = (j >= keep_from && j < keep_until) ? x[j] : 0.0f;  // (a select: drops NaN)
     }
 }
 
@@ -260,8 +263,8 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 template <typename DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ weight,
-                       const NodeG *__restrict__ coefs, typename DT::elem *__restrict__ grad_hidden, int V, int blank,
-                       long long total_rows) {
+                       const NodeG *__restrict__ coefs, typename DT::elem *__restrict__ grad_hidden, int V, int ldv,
+                       int padded, int blank, long long total_rows) {
     typedef typename DT::elem E;
     typedef typename Mma<DT>::frag frag;
     typedef Waits<1> W;
@@ -276,7 +279,9 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     const long long wg_row0 = (long long)blockIdx.x * kBM;
     const int wg_rows = (int)(total_rows - wg_row0 < kBM ? total_rows - wg_row0 : kBM);
     const int NT = (V + kBK - 1) / kBK;
-    auto tile_c0 = [&](int j) { return min(j * kBK, V - kBK); };  // the last tile overlaps its predecessor
+    // the last tile of a vocabulary that is no multiple of 32: in padded rows it runs on into the padding (entries
+    // from V on are masked), otherwise it starts at V - 32 and overlaps its predecessor (whose entries are masked)
+    auto tile_c0 = [&](int j) { return padded ? j * kBK : min(j * kBK, V - kBK); };
 
     // ---- producer side.  Gradient tile in LDS: [128 nodes][32 v], 64-byte rows, 16-byte chunk c of node n at
     // position c ^ ((n >> 2) & 3).  Thread tid owns the 16 bytes at tid * 16, in every step: its lane's DMA fetches
@@ -299,8 +304,8 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         cy = ok ? c1.y : -1;
     }
     // (rows past the end of the tensor: the last row's logits are fetched and ignored)
-    const unsigned l_voff = (unsigned)(((gr < wg_rows ? gr : wg_rows - 1) * V + 8 * gc) * 2);
-    const char *l_base = reinterpret_cast<const char *>(logits + (size_t)wg_row0 * V);
+    const unsigned l_voff = (unsigned)(((gr < wg_rows ? gr : wg_rows - 1) * ldv + 8 * gc) * 2);
+    const char *l_base = reinterpret_cast<const char *>(logits + (size_t)wg_row0 * ldv);
     __builtin_amdgcn_s_waitcnt(0x0070);  // the node record has landed: no compiler-visible load is in flight below
 
     // ---- consumer side ----
@@ -319,7 +324,8 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         if (k < kDmaPerStep) {
             const int t = j + 2 < NT ? j + 2 : NT - 1;  // (past the end: the last tile again; never read)
             const int kr = wave * kDmaPerStep + k;
-            const char *src = reinterpret_cast<const char *>(weight) + ((size_t)tile_c0(t) + kr) * kQRow;
+            // (weight rows past the vocabulary, padded rows only: the last row again, times g = 0)
+            const char *src = reinterpret_cast<const char *>(weight) + (size_t)min(tile_c0(t) + kr, V - 1) * kQRow;
 #ifndef FUSED_BWD_ABLATE_DMA
             if (j + 2 >= 0) lds_dma16(dma_voff(lane, k & 3), src, lds0 + kQ0 + ((j + 2) % kNQ) * kQBytes + kr * kQRow);
 #endif
@@ -345,7 +351,8 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     auto conv_finish = [&](int j) {
         const int c0 = tile_c0(j);
         const int vcol = c0 + 8 * gc;
-        grad8_fix(csyk, csbk, cy - vcol, blank - vcol, c0 != j * kBK, j * kBK - vcol, gx);
+        grad8_fix(csyk, csbk, cy - vcol, blank - vcol, padded ? c0 + kBK > V : c0 != j * kBK, padded ? 0 : j * kBK - vcol,
+                  padded ? V - vcol : 8, gx);
         *(lds_u128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16) = DT::pack(gx);
     };
     f32x16 acc[2][4];
@@ -416,7 +423,8 @@ template <typename DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ hidden,
                        const NodeG *__restrict__ coefs, float *__restrict__ partial, float *__restrict__ pbias, int V,
-                       int blank, long long total_rows, long long coef_rows, int nvb, int steps_per_chunk) {
+                       int ldv, int padded, int blank, long long total_rows, long long coef_rows, int nvb,
+                       int steps_per_chunk) {
     typedef typename Mma<DT>::frag frag;
     typedef Waits<2> W;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytesDw];
@@ -430,8 +438,10 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     const int vb = blockIdx.x % nvb;  // consecutive workgroups share a node range: its hidden rows stay in L2 / MALL
     const int rc = blockIdx.x / nvb;
     const int vmin = vb * kBM;
-    const int vb0 = min(vmin, V - kBM);  // the last vocabulary block overlaps its predecessor
-    const bool masked = vb0 != vmin;
+    // the last vocabulary block: runs on into the padding of padded rows, else overlaps its predecessor (as the
+    // last tile of rnnt_fused_bwd_dh)
+    const int vb0 = padded ? vmin : min(vmin, V - kBM);
+    const bool masked = padded ? vmin + kBM > V : vb0 != vmin;
     const long long row_begin = (long long)rc * steps_per_chunk * kBK;
     const long long rows_here = total_rows - row_begin;
     const int nsteps = rows_here <= 0 ? 0 : (int)min((long long)steps_per_chunk, (rows_here + kBK - 1) / kBK);
@@ -442,7 +452,7 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     const int gr = tid >> 4;
     const int gc = ((((tid >> 2) & 3) ^ (gr & 3)) << 2) | (tid & 3);
     const int vcol = vb0 + 8 * gc;
-    const int db = blank - vcol, keep_from = vmin - vcol;
+    const int db = blank - vcol, keep_from = padded ? 0 : vmin - vcol, keep_until = padded ? V - vcol : 8;
 
     // step j's DMAs, k = 0 .. 3: hidden row k of this wave's four of step j + 2; k = 4: logits, k = 5: node records of
     // step j + 4
@@ -466,8 +476,8 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
                 long long lrow = row0 + gr;
                 lrow = lrow < total_rows ? lrow : total_rows - 1;
                 const long long wrow0 = row0 + 4 * wave < total_rows ? row0 + 4 * wave : total_rows - 1;  // wave-uniform
-                const unsigned voff = (unsigned)(((lrow - wrow0) * V + vcol) * 2);  // 0 .. 3 rows on, this lane's chunk
-                lds_dma16(voff, reinterpret_cast<const char *>(logits) + (size_t)wrow0 * V * 2,
+                const unsigned voff = (unsigned)(((lrow - wrow0) * ldv + vcol) * 2);  // 0 .. 3 rows on, this lane's chunk
+                lds_dma16(voff, reinterpret_cast<const char *>(logits) + (size_t)wrow0 * ldv * 2,
                           lds0 + kG0 + slot * kGBytes + wave * 1024);
             } else {
                 // node records of the same four nodes: 128 bytes, fetched by lanes 0-31 (and again by lanes 32-63)
@@ -505,7 +515,7 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
                      "v"(fsyk), "v"(fsbk), "v"(fdy));
     };
     auto conv_finish = [&](int j) {
-        grad8_fix(fsyk, fsbk, fdy, db, masked, keep_from, gx);
+        grad8_fix(fsyk, fsbk, fdy, db, masked, keep_from, keep_until, gx);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bsum[e] += gx[e];
         *(lds_u128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16) = DT::pack(gx);
@@ -586,13 +596,14 @@ template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_fused_bwd_reduce(const float *__restrict__ partial,
                                                              const float *__restrict__ pbias,
                                                              typename DT::elem *__restrict__ grad_weight,
-                                                             float *__restrict__ grad_bias, int V, int nvb, int nchunks) {
+                                                             float *__restrict__ grad_bias, int V, int padded, int nvb,
+                                                             int nchunks) {
     const int v = blockIdx.x * 2 + (threadIdx.x >> 7);
     if (v >= V) return;
     const int col = (threadIdx.x & 127) * 4;
     const int last0 = V - kBM;  // first entry of the last (overlapping) block; it owns entries from (nvb-1)*128 on
     const int vb = v >= (nvb - 1) * kBM ? nvb - 1 : v / kBM;
-    const int local = vb == nvb - 1 ? v - last0 : v - vb * kBM;
+    const int local = (vb == nvb - 1 && !padded) ? v - last0 : v - vb * kBM;
     if (grad_weight) {
         f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int c = 0; c < nchunks; ++c)
@@ -653,10 +664,11 @@ BwdWorkspace carve_bwd(void *ws, const DwPlan &p) {
 
 template <typename DT>
 rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logits, const int *labels,
-                        const int *act_lens, const int *label_lens, int V, int B, const float *grad_out,
+                        const int *act_lens, const int *label_lens, int V, int ldv, int B, const float *grad_out,
                         int grad_out_stride, float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
                         const Lattice &L, void *bwd_ws, const rnntOptions &o) {
     typedef typename DT::elem E;
+    const int padded = ldv >= (V + kBM - 1) / kBM * kBM;  // every tile of every row may be read in full
     const long long rows = (long long)B * o.maxT * o.maxU;
     const DwPlan p = dw_plan(rows, V);
     const BwdWorkspace w = carve_bwd(bwd_ws, p);
@@ -669,14 +681,14 @@ rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logi
     if (grad_hidden)
         hipLaunchKernelGGL((rnnt_fused_bwd_dh<DT>), dim3((unsigned)row_tiles), dim3(kThreads), 0, st,
                            static_cast<const E *>(logits), static_cast<const E *>(weight), w.coefs,
-                           static_cast<E *>(grad_hidden), V, o.blank_label, rows);
+                           static_cast<E *>(grad_hidden), V, ldv, padded, o.blank_label, rows);
     if (o.stage_events && o.stage_events[2]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[2]), st);
     if (grad_weight || grad_bias) {
         hipLaunchKernelGGL((rnnt_fused_bwd_dw<DT>), dim3((unsigned)(p.nchunks * p.nvb)), dim3(kThreads), 0, st,
                            static_cast<const E *>(logits), static_cast<const E *>(hidden), w.coefs, w.partial, w.pbias, V,
-                           o.blank_label, rows, p.coef_rows, p.nvb, p.steps_per_chunk);
+                           ldv, padded, o.blank_label, rows, p.coef_rows, p.nvb, p.steps_per_chunk);
         hipLaunchKernelGGL((rnnt_fused_bwd_reduce<DT>), dim3((unsigned)((V + 1) / 2)), dim3(256), 0, st, w.partial,
-                           w.pbias, static_cast<E *>(grad_weight), grad_bias, V, p.nvb, p.nchunks);
+                           w.pbias, static_cast<E *>(grad_weight), grad_bias, V, padded, p.nvb, p.nchunks);
     }
     if (o.stage_events && o.stage_events[3]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[3]), st);
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
@@ -688,22 +700,27 @@ extern "C" {
 
 rnntStatus_t rnnt_joint_loss_backward_workspace_size(int hidden_size, int alphabet_size, int minibatch, int maxT,
                                                      int maxU, size_t *size_bytes) {
-    if (!size_bytes || hidden_size != kH || alphabet_size < kBM || alphabet_size % 8 != 0 || minibatch <= 0 || maxT <= 0 || maxU <= 0)
+    if (!size_bytes || hidden_size != kH || alphabet_size < kBM || minibatch <= 0 || maxT <= 0 || maxU <= 0)
         return RNNT_STATUS_INVALID_VALUE;
     const DwPlan p = dw_plan((long long)minibatch * maxT * maxU, alphabet_size);
     *size_bytes = carve_bwd(nullptr, p).bytes;
     return RNNT_STATUS_SUCCESS;
 }
 
-rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, const void *logits, const int *labels,
-                                      const int *act_lens, const int *label_lens, int hidden_size, int alphabet_size,
-                                      int minibatch, const float *grad_out, int grad_out_stride, float grad_scale,
-                                      void *grad_hidden, void *grad_weight, float *grad_bias, const void *workspace,
-                                      void *backward_workspace, rnntOptions options) {
+rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *weight, const void *logits,
+                                              int logits_row_stride, const int *labels, const int *act_lens,
+                                              const int *label_lens, int hidden_size, int alphabet_size, int minibatch,
+                                              const float *grad_out, int grad_out_stride, float grad_scale,
+                                              void *grad_hidden, void *grad_weight, float *grad_bias,
+                                              const void *workspace, void *backward_workspace, rnntOptions options) {
     if (!hidden || !weight || !logits || !act_lens || !label_lens || !workspace || !backward_workspace)
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
-    if (hidden_size != kH || alphabet_size < kBM || alphabet_size % 8 != 0) return RNNT_STATUS_INVALID_VALUE;
+    if (hidden_size != kH || alphabet_size < kBM) return RNNT_STATUS_INVALID_VALUE;
+    // every row of the logits starts on 16 bytes (LDS-DMA); rows without padding up to a multiple of 128 entries are
+    // read in overlapping tiles, whose starts must be 16-byte aligned too
+    if (logits_row_stride < alphabet_size || logits_row_stride % 8 != 0) return RNNT_STATUS_INVALID_VALUE;
+    if (logits_row_stride < (alphabet_size + kBM - 1) / kBM * kBM && alphabet_size % 8 != 0) return RNNT_STATUS_INVALID_VALUE;
     if (minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.maxU > RNNT_MAX_LATTICE_COLUMNS)
         return RNNT_STATUS_INVALID_VALUE;
     if (options.blank_label < 0 || options.blank_label >= alphabet_size) return RNNT_STATUS_INVALID_VALUE;
@@ -713,17 +730,28 @@ rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, co
         reinterpret_cast<uintptr_t>(logits) % 16 != 0 || reinterpret_cast<uintptr_t>(grad_hidden) % 16 != 0 ||
         reinterpret_cast<uintptr_t>(grad_weight) % 8 != 0 || reinterpret_cast<uintptr_t>(grad_bias) % 4 != 0)
         return RNNT_STATUS_INVALID_VALUE;
-    if ((size_t)kBM * alphabet_size * 2 > 0x7fffffffu) return RNNT_STATUS_INVALID_VALUE;  // one buffer range per row tile
+    if ((size_t)kBM * logits_row_stride * 2 > 0x7fffffffu) return RNNT_STATUS_INVALID_VALUE;  // 32-bit offsets per row tile
     const Lattice w = carve_workspace(const_cast<void *>(workspace), options.maxT, options.maxU, minibatch);
     if (options.stage_events && options.stage_events[0])
         (void)hipEventRecord(static_cast<hipEvent_t>(options.stage_events[0]), static_cast<hipStream_t>(options.stream));
     return options.dtype == RNNT_DTYPE_BF16
-               ? launch_bwd<BF16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
+               ? launch_bwd<BF16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                   grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
                                   options)
-               : launch_bwd<F16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
+               : launch_bwd<F16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                  grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
                                  options);
+}
+
+
+rnntStatus_t rnnt_joint_loss_backward(const void *hidden, const void *weight, const void *logits, const int *labels,
+                                      const int *act_lens, const int *label_lens, int hidden_size, int alphabet_size,
+                                      int minibatch, const float *grad_out, int grad_out_stride, float grad_scale,
+                                      void *grad_hidden, void *grad_weight, float *grad_bias, const void *workspace,
+                                      void *backward_workspace, rnntOptions options) {
+    return rnnt_joint_loss_backward_strided(hidden, weight, logits, alphabet_size, labels, act_lens, label_lens,
+                                            hidden_size, alphabet_size, minibatch, grad_out, grad_out_stride, grad_scale,
+                                            grad_hidden, grad_weight, grad_bias, workspace, backward_workspace, options);
 }
 
 }  // extern "C"

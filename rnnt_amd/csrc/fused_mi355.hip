@@ -232,6 +232,7 @@ struct StoreLane {   // where this lane stores after the transpose through LDS
     unsigned xr;     // LDS byte address it READS a 16-byte piece from: xbuf + (l >> 2) * kXPitch + (l & 3) * 16
     unsigned voff;   // byte offset in the workgroup's 256 logits rows: (32 wave + (l >> 2)) * 2V + (l & 3) * 16
     char *base; unsigned nbytes;
+    int ldv;         // elements between consecutive rows of the logits tensor
     __amdgpu_buffer_rsrc_t rows;  // the workgroup's rows of the logits tensor (rows past the end are out of range:
                                   // the hardware drops those stores, every wave still issues the same number)
 };
@@ -310,13 +311,13 @@ __device__ __forceinline__ void tile_epilogue_impl(const f32x16 (&acc)[2], RowSt
                 // sc1: written through and not kept in the XCD's L2, which the weight tiles need (4.3 MB of
                 // weights per 4 MiB L2, re-read by every workgroup, against 4.4 GB of logits passing through)
 #ifdef FUSED_ABLATE_GSTORE
-                if ((size_t)sl.voff + (size_t)k * 16 * V * 2 < (size_t)sl.nbytes)
-                    *reinterpret_cast<u32x4 *>(sl.base + sl.voff + (size_t)(k * 16 * V + c0 + t * 32) * 2) = o;
+                if ((size_t)sl.voff + (size_t)k * 16 * sl.ldv * 2 < (size_t)sl.nbytes)
+                    *reinterpret_cast<u32x4 *>(sl.base + sl.voff + (size_t)(k * 16 * sl.ldv + c0 + t * 32) * 2) = o;
 #else
                 // (whole offset in the VGPR operand: with a scalar offset register hipcc lets a vector
                 // instruction overwrite the data registers in the cycle after the store, and on gfx950 the
                 // store then picks up the new values: 1 in 10^5 elements came out wrong)
-                __builtin_amdgcn_raw_buffer_store_b128(o, sl.rows, sl.voff + (unsigned)((k * 16 * V + c0 + t * 32) * 2), 0,
+                __builtin_amdgcn_raw_buffer_store_b128(o, sl.rows, sl.voff + (unsigned)((k * 16 * sl.ldv + c0 + t * 32) * 2), 0,
                                                        FUSED_STORE_AUX);
 #endif
 #ifdef FUSED_ABLATE_DBGWAIT
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const typename DT::elem *__restrict__ weight,
                         const float *__restrict__ bias, typename DT::elem *__restrict__ logits,
                         const int *__restrict__ labels, const int *__restrict__ act_lens,
-                        const int *__restrict__ label_lens, Lattice L, int maxT, int U1, int V, int blank,
+                        const int *__restrict__ label_lens, Lattice L, int maxT, int U1, int V, int ldv, int blank,
                         long long total_rows, long long row_tile0, int vsplit, float2 *__restrict__ partial) {
     typedef TileBuf<H> TB;
     typedef typename Mma<DT>::frag frag;
@@ -389,19 +390,27 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     if (!lead) stage_tile<DT, H>(weight, bias, min(n0 * kBN, V - kBN), lds0, part, lane);
 
     RowStat st = {-INFINITY, 0.0f};
-    E *out_row = logits + (size_t)ld_row * (size_t)V;
+    E *out_row = logits + (size_t)ld_row * (size_t)ldv;  // ldv: elements from one node's row to the next (>= V)
     StoreLane sl;
     {
         const unsigned xbuf = lds0 + 2 * TB::kBytes + wave * kXBytes;
         sl.xw = xbuf + r * kXPitch + 8 * h;
         sl.xr = xbuf + (lane >> 2) * kXPitch + (lane & 3) * 16;
-        sl.voff = (unsigned)((wave * kRowsPerWave + (lane >> 2)) * V * 2 + (lane & 3) * 16);
+        sl.voff = (unsigned)((wave * kRowsPerWave + (lane >> 2)) * ldv * 2 + (lane & 3) * 16);
         const long long wg_row0 = row_tile * kBM;
         const long long wg_rows = total_rows - wg_row0 < kBM ? total_rows - wg_row0 : kBM;
-        sl.base = reinterpret_cast<char *>(logits) + (size_t)wg_row0 * V * 2;
-        sl.nbytes = (unsigned)(wg_rows * V * 2);
-        sl.rows = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(logits) + (size_t)wg_row0 * V * 2, (short)0,
-                                                    (int)(wg_rows * V * 2), 0x00020000);
+        sl.base = reinterpret_cast<char *>(logits) + (size_t)wg_row0 * ldv * 2;
+        sl.nbytes = (unsigned)(wg_rows * ldv * 2);
+        sl.ldv = ldv;
+        int store_bytes = (int)(wg_rows * ldv * 2);
+#ifdef FUSED_ABLATE_STORE_LEAD  // timing only: the hardware drops the stores of waves 0-3 (out of range)
+        if (lead) store_bytes = 0;
+#endif
+#ifdef FUSED_ABLATE_STORE_LOADER
+        if (!lead) store_bytes = 0;
+#endif
+        sl.rows = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(logits) + (size_t)wg_row0 * ldv * 2, (short)0,
+                                                    store_bytes, 0x00020000);
     }
 
     f32x16 acc[2];
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict
                                                         const int *__restrict__ labels,
                                                         const int *__restrict__ act_lens,
                                                         const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-                                                        int V, int blank) {
+                                                        int V, int ldv, int blank) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long row = row0 + (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     if (row >= total_rows) return;  // wave-uniform
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict
     const bool emit = c.u < Ub;
     const int y = emit ? labels[(size_t)c.b * (U1 - 1) + c.u] : blank;
     const bool y_ok = y >= 0 && y < V;
-    const typename DT::elem *out_row = logits + (size_t)row * (size_t)V;
+    const typename DT::elem *out_row = logits + (size_t)row * (size_t)ldv;
     const float xb = DT::to_float(out_row[blank]);
     const float xy = y_ok ? DT::to_float(out_row[y]) : __builtin_nanf("");
 
@@ -558,7 +567,7 @@ int compute_units() {
 
 template <typename DT, int H>
 rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *bias, void *logits,
-                          const int *labels, const int *act_lens, const int *label_lens, int V, int B,
+                          const int *labels, const int *act_lens, const int *label_lens, int V, int ldv, int B,
                           const Lattice &L, const rnntOptions &o) {
     typedef typename DT::elem E;
     const long long rows = (long long)B * o.maxT * o.maxU;
@@ -590,7 +599,7 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
     float2 *partial = reinterpret_cast<float2 *>(L.alpha);
 #define FUSED_ARGS                                                                                            \
     static_cast<const E *>(hidden), static_cast<const E *>(weight), bias, static_cast<E *>(logits), labels,   \
-        act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows
+        act_lens, label_lens, L, o.maxT, o.maxU, V, ldv, o.blank_label, rows
 #define FUSED_LAUNCH(NWG, TILE0, SPLIT)                                                                      \
     hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st, FUSED_ARGS, \
                        (long long)(TILE0), (int)(SPLIT), partial)
@@ -600,7 +609,7 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
         const long long row0 = full * kBM, n = rows - row0;
         hipLaunchKernelGGL((rnnt_fused_merge<DT>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, vsplit,
                            row0, rows, static_cast<const E *>(logits), labels, act_lens, label_lens, L, o.maxT, o.maxU, V,
-                           o.blank_label);
+                           ldv, o.blank_label);
     }
 #undef FUSED_LAUNCH
 #undef FUSED_ARGS
@@ -609,12 +618,12 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
 
 template <typename DT>
 rnntStatus_t launch_fused_h(int H, const void *hidden, const void *weight, const float *bias, void *logits,
-                            const int *labels, const int *act_lens, const int *label_lens, int V, int B,
+                            const int *labels, const int *act_lens, const int *label_lens, int V, int ldv, int B,
                             const Lattice &L, const rnntOptions &o) {
     switch (H) {
-        case 512: return launch_fused<DT, 512>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, B, L, o);
-        case 256: return launch_fused<DT, 256>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, B, L, o);
-        case 128: return launch_fused<DT, 128>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, B, L, o);
+        case 512: return launch_fused<DT, 512>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
+        case 256: return launch_fused<DT, 256>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
+        case 128: return launch_fused<DT, 128>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }
@@ -629,10 +638,14 @@ int rnnt_fused_debug_set_stamp_buffer(void *p) {
 }
 #endif
 
-rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, const float *bias, void *logits_out,
-                                     const int *labels, const int *act_lens, const int *label_lens,
-                                     int hidden_size, int alphabet_size, int minibatch, float *costs,
-                                     float *loss_out, int reduction, void *workspace, rnntOptions options) {
+rnntStatus_t rnnt_joint_loss_forward_strided(const void *hidden, const void *weight, const float *bias,
+                                             void *logits_out, int logits_row_stride, const int *labels,
+                                             const int *act_lens, const int *label_lens, int hidden_size,
+                                             int alphabet_size, int minibatch, float *costs, float *loss_out,
+                                             int reduction, void *workspace, rnntOptions options) {
+    if (logits_row_stride < alphabet_size) return RNNT_STATUS_INVALID_VALUE;
+    // (a workgroup's 256 rows are addressed with 32-bit byte offsets)
+    if ((long long)logits_row_stride * 2 * kBM > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     if (!hidden || !weight || !bias || !logits_out || !act_lens || !label_lens || !workspace || !costs)
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
@@ -652,11 +665,21 @@ rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, con
     const rnntStatus_t s =
         options.dtype == RNNT_DTYPE_BF16
             ? launch_fused_h<BF16>(hidden_size, hidden, weight, bias, logits_out, labels, act_lens, label_lens,
-                                   alphabet_size, minibatch, w, options)
+                                   alphabet_size, logits_row_stride, minibatch, w, options)
             : launch_fused_h<F16>(hidden_size, hidden, weight, bias, logits_out, labels, act_lens, label_lens,
-                                  alphabet_size, minibatch, w, options);
+                                  alphabet_size, logits_row_stride, minibatch, w, options);
     if (s != RNNT_STATUS_SUCCESS) return s;
     return launch_lattice_and_costs(act_lens, label_lens, minibatch, costs, loss_out, reduction, w, options);
+}
+
+
+rnntStatus_t rnnt_joint_loss_forward(const void *hidden, const void *weight, const float *bias, void *logits_out,
+                                     const int *labels, const int *act_lens, const int *label_lens,
+                                     int hidden_size, int alphabet_size, int minibatch, float *costs,
+                                     float *loss_out, int reduction, void *workspace, rnntOptions options) {
+    return rnnt_joint_loss_forward_strided(hidden, weight, bias, logits_out, alphabet_size, labels, act_lens, label_lens,
+                                           hidden_size, alphabet_size, minibatch, costs, loss_out, reduction, workspace,
+                                           options);
 }
 
 }  // extern "C"

@@ -5,8 +5,13 @@ The reference runs ``Linear(inner_dim -> vocab)`` as the last layer of ``JointNe
 (/root/reference/src/rnnt/model.py:14-18, applied at :59) and hands the ``[B,T,U+1,V]`` logits to
 ``RNNTLoss`` (:116).  For 16-bit operands this module does both with ``rnnt_joint_loss_forward``
 (include/rnnt_mi355.h): one MFMA kernel writes the logits once and produces the log-softmax statistics
-in its epilogue, so the loss's first pass over the logits (K1) does not exist.  Backward is K3 on the
-stored logits followed by the two plain library GEMMs of a Linear layer's backward.
+in its epilogue, so the loss's first pass over the logits (K1) does not exist.  Backward is
+``rnnt_joint_loss_backward``: two MFMA kernels that form the loss's gradient tile by tile from the stored logits
+(K3's arithmetic as their prologue) and multiply it at once, so the gradient w.r.t. the logits is never written
+(inner size 512, vocabulary >= 128; other shapes: K3 followed by the two plain library GEMMs of a Linear layer's
+backward).  On the fused-backward path the logits are kept with their rows padded to a multiple of 128 entries:
+every row then starts on a 256-byte boundary, which the forward kernel's stores and the backward kernels' LDS-DMA
+reads want (13 % of the forward at V = 4232, profiles/r03_tuning.md), and any vocabulary size is taken.
 
 This is an EXTENSION next to the drop-in, not part of it: its inputs are the hidden activations and the
 projection's parameters, not logits.  No CPU path, no fallback.
@@ -30,7 +35,14 @@ DEFAULT_MIN_NODES = 16384
 
 def fused_backward_supported(H: int, V: int) -> bool:
     """Shapes ``rnnt_joint_loss_backward`` takes (include/rnnt_mi355.h); others run K3 + two library GEMMs."""
-    return H == 512 and V >= 128 and V % 8 == 0
+    return H == 512 and V >= 128
+
+
+def _row_stride(H: int, V: int, fused_backward: bool) -> int:
+    """Elements from one node's row of the stored logits to the next."""
+    if fused_backward and fused_backward_supported(H, V):
+        return (V + 127) // 128 * 128
+    return V  # K3 (rnnt_backward) reads contiguous rows
 
 
 class _FusedJointLossFunction(torch.autograd.Function):
@@ -44,21 +56,23 @@ class _FusedJointLossFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             bias32 = bias.detach().to(torch.float32).contiguous()
-            logits = torch.empty((B, T, U1, V), dtype=hidden.dtype, device=dev)
+            ld = _row_stride(H, V, fused_backward)
+            logits = torch.empty((B * T * U1, ld), dtype=hidden.dtype, device=dev)  # (columns V .. ld-1: never touched)
             ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             loss = torch.empty(B if red == _lib.REDUCTION_NONE else 1, dtype=torch.float32, device=dev)
             opts = _lib.RnntOptions(stream, int(blank), T, U1, _DTYPES[hidden.dtype], None)
-            _lib.check(lib.rnnt_joint_loss_forward(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
-                                                   logits.data_ptr(), labels.data_ptr(), act_lens.data_ptr(),
-                                                   label_lens.data_ptr(), H, V, B, costs.data_ptr(),
-                                                   loss.data_ptr(), red, ws.data_ptr(), opts),
-                       "rnnt_joint_loss_forward")
+            _lib.check(lib.rnnt_joint_loss_forward_strided(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
+                                                           logits.data_ptr(), ld, labels.data_ptr(),
+                                                           act_lens.data_ptr(), label_lens.data_ptr(), H, V, B,
+                                                           costs.data_ptr(), loss.data_ptr(), red, ws.data_ptr(), opts),
+                       "rnnt_joint_loss_forward_strided")
         ctx.save_for_backward(hidden, weight, logits, labels, act_lens, label_lens, ws)
         ctx.blank = int(blank)
         ctx.reduction = red
         ctx.bias_dtype = bias.dtype
         ctx.fused_backward = bool(fused_backward)
+        ctx.dims = (B, T, U1, V, ld)
         return loss
 
     @staticmethod
@@ -66,7 +80,7 @@ class _FusedJointLossFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         hidden, weight, logits, labels, act_lens, label_lens, ws = ctx.saved_tensors
         lib = _lib.load()
-        B, T, U1, V = logits.shape
+        B, T, U1, V, ld = ctx.dims
         H = hidden.shape[-1]
         dev = logits.device
         with torch.cuda.device(dev):
@@ -90,15 +104,16 @@ class _FusedJointLossFunction(torch.autograd.Function):
                 if need_w:
                     g_weight = torch.empty_like(weight)
                 gb32 = torch.empty(V, dtype=torch.float32, device=dev) if need_b else None
-                _lib.check(lib.rnnt_joint_loss_backward(
-                    hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), labels.data_ptr(), act_lens.data_ptr(),
-                    label_lens.data_ptr(), H, V, B, go.data_ptr(), stride, ctypes.c_float(scale),
+                _lib.check(lib.rnnt_joint_loss_backward_strided(
+                    hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), ld, labels.data_ptr(),
+                    act_lens.data_ptr(), label_lens.data_ptr(), H, V, B, go.data_ptr(), stride, ctypes.c_float(scale),
                     g_hidden.data_ptr() if need_h else None, g_weight.data_ptr() if need_w else None,
                     gb32.data_ptr() if need_b else None, ws.data_ptr(), bws.data_ptr(), opts),
-                    "rnnt_joint_loss_backward")
+                    "rnnt_joint_loss_backward_strided")
                 if need_b:
                     g_bias = gb32.to(ctx.bias_dtype)
             else:
+                assert ld == V
                 g_logits = torch.empty_like(logits)
                 _lib.check(lib.rnnt_backward(logits.data_ptr(), g_logits.data_ptr(), labels.data_ptr(),
                                              act_lens.data_ptr(), label_lens.data_ptr(), V, B, go.data_ptr(), stride,

@@ -37,8 +37,10 @@ def make_inputs(B, T, U, V, H, dtype, seed, ragged=True):
     return hidden, weight, bias, labels, al, ll
 
 
-def forward_c_abi(hidden, weight, bias, labels, al, ll, reduction=0):
-    """rnnt_joint_loss_forward as a C caller would use it; returns (logits_out, costs, workspace)."""
+def forward_c_abi(hidden, weight, bias, labels, al, ll, reduction=0, ld=None):
+    """rnnt_joint_loss_forward as a C caller would use it; returns (status, logits_out, costs, workspace).
+    ``ld``: rnnt_joint_loss_forward_strided with that row stride; logits_out is then [B, T, U+1, ld], NaN-filled
+    before the call (columns V .. ld-1 must come back untouched)."""
     from rnnt_amd import _lib
     from rnnt_amd.loss import _DTYPES
 
@@ -48,13 +50,18 @@ def forward_c_abi(hidden, weight, bias, labels, al, ll, reduction=0):
     h, w = hidden.to(DEV).contiguous(), weight.to(DEV).contiguous()
     b32 = bias.to(DEV).float().contiguous()
     lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
-    logits = torch.full((B, T, U1, V), float("nan"), dtype=hidden.dtype, device=DEV)
+    logits = torch.full((B, T, U1, V if ld is None else ld), float("nan"), dtype=hidden.dtype, device=DEV)
     costs = torch.empty(B, dtype=torch.float32, device=DEV)
     ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=DEV)
     opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, T, U1, _DTYPES[hidden.dtype], None)
-    st = lib.rnnt_joint_loss_forward(h.data_ptr(), w.data_ptr(), b32.data_ptr(), logits.data_ptr(), lab.data_ptr(),
-                                     ald.data_ptr(), lld.data_ptr(), H, V, B, costs.data_ptr(), None, reduction,
-                                     ws.data_ptr(), opts)
+    if ld is None:
+        st = lib.rnnt_joint_loss_forward(h.data_ptr(), w.data_ptr(), b32.data_ptr(), logits.data_ptr(), lab.data_ptr(),
+                                         ald.data_ptr(), lld.data_ptr(), H, V, B, costs.data_ptr(), None, reduction,
+                                         ws.data_ptr(), opts)
+    else:
+        st = lib.rnnt_joint_loss_forward_strided(h.data_ptr(), w.data_ptr(), b32.data_ptr(), logits.data_ptr(), ld,
+                                                 lab.data_ptr(), ald.data_ptr(), lld.data_ptr(), H, V, B,
+                                                 costs.data_ptr(), None, reduction, ws.data_ptr(), opts)
     torch.cuda.synchronize()
     return st, logits, costs, ws
 
@@ -75,6 +82,34 @@ def check_logits(logits, hidden, weight, bias, min_exact=0.999):
     acc_err = 2e-6 * torch.nn.functional.linear(hidden.double().abs(), weight.double().abs(), bias.double().abs())
     worst = float((((got.double() - ref64).abs() - acc_err).clamp_min(0) / spacing).max())
     assert worst <= 0.55, worst
+
+
+@pytest.mark.parametrize("B,T,U,V,ld,H,dtype", [
+    (2, 9, 4, 4232, 4352, 512, torch.bfloat16),     # what rnnt_amd.FusedJointLoss allocates: rows on 256-byte boundaries
+    (3, 33, 7, 4234, 4288, 512, torch.bfloat16),    # odd vocabulary, rows on 128-byte lines
+    (2, 21, 5, 5455, 5457, 512, torch.float16),     # a stride that aligns nothing
+    (4, 70, 12, 1000, 1024, 128, torch.float16),    # several workgroups, the surplus rule, H = 128
+    (1, 40, 6, 64, 200, 256, torch.bfloat16),
+])
+def test_fused_forward_with_padded_rows(B, T, U, V, ld, H, dtype):
+    """rnnt_joint_loss_forward_strided: the same logits (bit for bit), costs and lattice planes as the contiguous
+    call, written at the row stride; the padding of every row stays untouched."""
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, H, dtype, seed=V + H + T)
+    st, ref_logits, ref_costs, ref_ws = forward_c_abi(hidden, weight, bias, labels, al, ll)
+    assert st == 0
+    st, logits, costs, ws = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=ld)
+    assert st == 0
+    assert torch.equal(logits[..., :V].contiguous().view(torch.int16), ref_logits.view(torch.int16))
+    assert bool(torch.isnan(logits[..., V:].float()).all())
+    assert torch.equal(costs, ref_costs)
+    from rnnt_amd import _lib
+
+    lib = _lib.load()
+    opts = _lib.RnntOptions(None, 0, T, U + 1, 1, None)
+    args = (hidden.to(DEV).data_ptr(), weight.to(DEV).data_ptr(), bias.to(DEV).float().data_ptr(), logits.data_ptr())
+    tail = (torch.from_numpy(labels).to(DEV).data_ptr(), torch.from_numpy(al).to(DEV).data_ptr(),
+            torch.from_numpy(ll).to(DEV).data_ptr(), H, V, B, costs.data_ptr(), None, 0, ws.data_ptr(), opts)
+    assert lib.rnnt_joint_loss_forward_strided(*args, V - 1, *tail) == 2     # stride shorter than a row
 
 
 @pytest.mark.parametrize("B,T,U,V,H,dtype", [

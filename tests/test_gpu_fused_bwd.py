@@ -25,8 +25,10 @@ from test_gpu_fused import DEV, EPS, forward_c_abi, make_inputs
 pytestmark = pytest.mark.gpu
 
 
-def backward_c_abi(hidden, weight, logits, labels, al, ll, ws, go, stride, scale, blank=0, want=(True, True, True)):
-    """rnnt_joint_loss_backward as a C caller would use it; returns (status, grad_hidden, grad_weight, grad_bias)."""
+def backward_c_abi(hidden, weight, logits, labels, al, ll, ws, go, stride, scale, blank=0, want=(True, True, True),
+                   ld=None):
+    """rnnt_joint_loss_backward as a C caller would use it; returns (status, grad_hidden, grad_weight, grad_bias).
+    ``ld``: rnnt_joint_loss_backward_strided on logits whose rows are ``ld`` elements apart."""
     from rnnt_amd import _lib
     from rnnt_amd.loss import _DTYPES
 
@@ -45,10 +47,15 @@ def backward_c_abi(hidden, weight, logits, labels, al, ll, ws, go, stride, scale
     db = torch.full((V,), float("nan"), dtype=torch.float32, device=DEV) if want[2] else None
     god = torch.as_tensor(go, dtype=torch.float32, device=DEV).reshape(-1)
     opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, blank, T, U1, _DTYPES[hidden.dtype], None)
-    st = lib.rnnt_joint_loss_backward(h.data_ptr(), w.data_ptr(), logits.data_ptr(), lab.data_ptr(), ald.data_ptr(),
-                                      lld.data_ptr(), H, V, B, god.data_ptr(), stride, ctypes.c_float(scale),
-                                      dh.data_ptr() if want[0] else None, dw.data_ptr() if want[1] else None,
-                                      db.data_ptr() if want[2] else None, ws.data_ptr(), bws.data_ptr(), opts)
+    outs = (dh.data_ptr() if want[0] else None, dw.data_ptr() if want[1] else None, db.data_ptr() if want[2] else None,
+            ws.data_ptr(), bws.data_ptr(), opts)
+    if ld is None:
+        st = lib.rnnt_joint_loss_backward(h.data_ptr(), w.data_ptr(), logits.data_ptr(), lab.data_ptr(), ald.data_ptr(),
+                                          lld.data_ptr(), H, V, B, god.data_ptr(), stride, ctypes.c_float(scale), *outs)
+    else:
+        st = lib.rnnt_joint_loss_backward_strided(h.data_ptr(), w.data_ptr(), logits.data_ptr(), ld, lab.data_ptr(),
+                                                  ald.data_ptr(), lld.data_ptr(), H, V, B, god.data_ptr(), stride,
+                                                  ctypes.c_float(scale), *outs)
     torch.cuda.synchronize()
     return st, dh, dw, db
 
@@ -148,6 +155,53 @@ def test_fused_backward_equals_k3_then_two_products(B, T, U, V, dtype, blank, wh
     check_against_k3(hidden, weight, g, None, dw2, db2)
 
 
+STRIDED = [
+    # B, T, U, V, ld, dtype, what
+    (2, 9, 4, 4232, 4352, torch.bfloat16, "what rnnt_amd.FusedJointLoss allocates for the reference's vocabulary"),
+    (3, 33, 7, 4234, 4352, torch.bfloat16, "the reference's 4234: no multiple of 8; whole tiles, masked from V on"),
+    (2, 21, 5, 5455, 5504, torch.float16, "config/magic_*.yaml's 5455, odd; fp16"),
+    (2, 17, 3, 130, 256, torch.bfloat16, "two vocabulary blocks, the second holds two entries"),
+    (4, 70, 12, 1000, 1024, torch.float16, "several row tiles and node ranges; the last chunk straddles V"),
+    (3, 33, 7, 4240, 4248, torch.bfloat16, "a stride without whole-tile padding: overlapping last tile and block"),
+    (1, 40, 6, 128, 128, torch.bfloat16, "stride = V through the strided entry"),
+]
+
+
+@pytest.mark.parametrize("B,T,U,V,ld,dtype,what", STRIDED)
+def test_fused_backward_on_padded_rows(B, T, U, V, ld, dtype, what):
+    """rnnt_joint_loss_backward_strided on the logits rnnt_joint_loss_forward_strided stored (padding: NaN) against
+    rnnt_backward on a contiguous copy of the same logits + the float64 products."""
+    H = 512
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, H, dtype, seed=V + T + 1)
+    st, logits, costs, ws = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=ld)
+    assert st == 0, what
+    for b in range(B):                                   # padding nodes, too
+        logits[b, al[b]:] = float("nan")
+        logits[b, :, ll[b] + 1:] = float("inf")
+    dense = logits[..., :V].contiguous()
+    go = np.linspace(0.25, 1.5, B).astype(np.float32)
+    g = k3_c_abi(dense, labels, al, ll, ws, go, 1, 1.0)
+    st, dh, dw, db = backward_c_abi(hidden, weight, logits, labels, al, ll, ws, go, 1, 1.0, ld=ld)
+    assert st == 0, what
+    check_against_k3(hidden, weight, g, dh, dw, db)
+    if ld == V or V % 8 == 0:
+        # the contiguous entry point on the contiguous copy: the same bits
+        st, dh2, dw2, db2 = backward_c_abi(hidden, weight, dense, labels, al, ll, ws, go, 1, 1.0)
+        assert st == 0
+        assert torch.equal(dh, dh2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_fused_backward_stride_checks():
+    hidden, weight, bias, labels, al, ll = make_inputs(1, 4, 2, 4234, 512, torch.bfloat16, seed=1)
+    st, logits, _, ws = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=4352)
+    assert st == 0
+    call = lambda ld: backward_c_abi(hidden, weight, logits, labels, al, ll, ws, [1.0], 0, 1.0, ld=ld)[0]
+    assert call(4352) == 0
+    assert call(4240) == 2      # rows not padded to whole tiles and V no multiple of 8: overlapping tiles unaligned
+    assert call(4354) == 2      # rows must start on 16 bytes
+    assert call(4232) == 2      # shorter than a row
+
+
 def _forward_blank(hidden, weight, bias, labels, al, ll, blank):
     """The unfused forward (library GEMM + rnnt_forward) with a blank other than 0; same workspace layout."""
     from rnnt_amd import _lib
@@ -186,9 +240,8 @@ def test_fused_backward_argument_checks():
     n = ctypes.c_size_t(0)
     assert lib.rnnt_joint_loss_backward_workspace_size(256, 4232, 2, 10, 5, ctypes.byref(n)) == 2    # H
     assert lib.rnnt_joint_loss_backward_workspace_size(512, 100, 2, 10, 5, ctypes.byref(n)) == 2     # V < 128
-    # rows of the logits that are not 16-byte aligned (the reference's 4234 and 5455): the LDS-DMA path is not taken;
-    # rnnt_amd.FusedJointLoss runs rnnt_backward + two library GEMMs for them
-    assert lib.rnnt_joint_loss_backward_workspace_size(512, 4234, 2, 10, 5, ctypes.byref(n)) == 2
+    # (the reference's 4234 and 5455 are taken through rnnt_joint_loss_backward_strided on padded rows)
+    assert lib.rnnt_joint_loss_backward_workspace_size(512, 4234, 2, 10, 5, ctypes.byref(n)) == 0
     assert lib.rnnt_joint_loss_backward_workspace_size(512, 4232, 2, 10, 5, ctypes.byref(n)) == 0 and n.value > 0
     hidden, weight, bias, labels, al, ll = make_inputs(1, 4, 2, 128, 512, torch.bfloat16, seed=1)
     st, logits, _, ws = forward_c_abi(hidden, weight, bias, labels, al, ll)
@@ -210,6 +263,7 @@ def test_fused_backward_argument_checks():
     assert call(256, 128, _lib.DTYPE_BF16) == 2
     assert call(512, 64, _lib.DTYPE_BF16) == 2
     assert call(512, 128, _lib.DTYPE_BF16, bw=None) == 2
+    assert call(512, 130, _lib.DTYPE_BF16) == 2        # contiguous rows of a vocabulary that is no multiple of 8
     assert call(512, 128, _lib.DTYPE_BF16) == 0
     torch.cuda.synchronize()
 

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only-backward", action="store_true", help="stage times of rnnt_joint_loss_backward only")
+    ap.add_argument("--only-forward", action="store_true", help="the fused forward only (tuning A/B runs)")
     args = ap.parse_args()
     import rnnt_amd
 
@@ -97,15 +98,17 @@ def main():
         lib = _lib.load()
         U1 = U + 1
         with torch.no_grad():
-            logits = torch.empty(B, T, U1, V, dtype=dt, device=dev)
+            ld = (V + 127) // 128 * 128      # the row stride rnnt_amd.FusedJointLoss keeps the logits at
+            logits = torch.empty(B * T * U1, ld, dtype=dt, device=dev)
             ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=dev)
             costs = torch.empty(B, device=dev)
             b32 = proj.bias.float().contiguous()
             st = torch.cuda.current_stream().cuda_stream
             opts = _lib.RnntOptions(st, 0, T, U1, _DTYPES[dt], None)
-            _lib.check(lib.rnnt_joint_loss_forward(hidden.data_ptr(), proj.weight.data_ptr(), b32.data_ptr(),
-                                                   logits.data_ptr(), labels.data_ptr(), al.data_ptr(), ll.data_ptr(),
-                                                   H, V, B, costs.data_ptr(), None, 0, ws.data_ptr(), opts), "fwd")
+            _lib.check(lib.rnnt_joint_loss_forward_strided(hidden.data_ptr(), proj.weight.data_ptr(), b32.data_ptr(),
+                                                           logits.data_ptr(), ld, labels.data_ptr(), al.data_ptr(),
+                                                           ll.data_ptr(), H, V, B, costs.data_ptr(), None, 0,
+                                                           ws.data_ptr(), opts), "fwd")
             n = ctypes.c_size_t(0)
             _lib.check(lib.rnnt_joint_loss_backward_workspace_size(H, V, B, T, U1, ctypes.byref(n)), "size")
             bws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
@@ -115,8 +118,8 @@ def main():
             opts = _lib.RnntOptions(st, 0, T, U1, _DTYPES[dt], ev.ptr())
             rows = []
             for _ in range(args.reps + 3):
-                _lib.check(lib.rnnt_joint_loss_backward(hidden.data_ptr(), proj.weight.data_ptr(), logits.data_ptr(),
-                                                        labels.data_ptr(), al.data_ptr(), ll.data_ptr(), H, V, B,
+                _lib.check(lib.rnnt_joint_loss_backward_strided(hidden.data_ptr(), proj.weight.data_ptr(), logits.data_ptr(),
+                                                        ld, labels.data_ptr(), al.data_ptr(), ll.data_ptr(), H, V, B,
                                                         go.data_ptr(), 0, ctypes.c_float(1.0 / B), dh.data_ptr(),
                                                         dw.data_ptr(), db.data_ptr(), ws.data_ptr(), bws.data_ptr(),
                                                         opts), "bwd")
@@ -130,6 +133,11 @@ def main():
                 "workspace_MB": round(int(n.value) / 1e6, 1)}
 
     from rnnt_amd.fused import fused_backward_supported
+    if args.only_forward:
+        ms = median_ms(fused_fwd, args.reps)
+        print(json.dumps({"shape": [B, T, U, V, H], "dtype": args.dtype, "fused_forward_ms": round(ms, 4),
+                          "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1)}))
+        return
     if args.only_backward:
         print(json.dumps({"shape": [B, T, U, V, H], "dtype": args.dtype, "fused_backward_stage_ms": backward_stages()}))
         return
