@@ -264,7 +264,8 @@ template <typename DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ weight,
                        const NodeG *__restrict__ coefs, typename DT::elem *__restrict__ grad_hidden, int V, int ldv,
-                       int padded, int blank, long long total_rows) {
+                       int padded, int blank, long long total_rows, long long row_tile0, int vsplit,
+                       float *__restrict__ split_partial) {
     typedef typename DT::elem E;
     typedef typename Mma<DT>::frag frag;
     typedef Waits<1> W;
@@ -276,12 +277,19 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const long long wg_row0 = (long long)blockIdx.x * kBM;
+    // vsplit = 1: workgroup b owns row tile row_tile0 + b and walks the whole vocabulary.  vsplit = S > 1 (the surplus
+    // row tiles of a launch that does not fill a whole round of CUs, see launch_bwd): S workgroups share a row tile,
+    // each walks 1/S of the vocabulary tiles and leaves its fp32 sums in `split_partial` for rnnt_fused_bwd_dh_merge.
+    const long long wg_row0 = (row_tile0 + blockIdx.x / vsplit) * kBM;
+    const int split = blockIdx.x % vsplit;
     const int wg_rows = (int)(total_rows - wg_row0 < kBM ? total_rows - wg_row0 : kBM);
-    const int NT = (V + kBK - 1) / kBK;
-    // the last tile of a vocabulary that is no multiple of 32: in padded rows it runs on into the padding (entries
-    // from V on are masked), otherwise it starts at V - 32 and overlaps its predecessor (whose entries are masked)
-    auto tile_c0 = [&](int j) { return padded ? j * kBK : min(j * kBK, V - kBK); };
+    const int NT_all = (V + kBK - 1) / kBK;
+    const int jt0 = (int)((long long)split * NT_all / vsplit);                 // first vocabulary tile of this workgroup
+    const int NT = (int)((long long)(split + 1) * NT_all / vsplit) - jt0;      // its number of tiles (>= 1: vsplit <= NT_all)
+    // Tile j of this workgroup is vocabulary tile jt0 + j.  The last tile of a vocabulary that is no multiple of 32: in
+    // padded rows it runs on into the padding (entries from V on are masked), otherwise it starts at V - 32 and
+    // overlaps its predecessor (whose entries are masked)
+    auto tile_c0 = [&](int j) { return padded ? (jt0 + j) * kBK : min((jt0 + j) * kBK, V - kBK); };
 
     // ---- producer side.  Gradient tile in LDS: [128 nodes][32 v], 64-byte rows, 16-byte chunk c of node n at
     // position c ^ ((n >> 2) & 3).  Thread tid owns the 16 bytes at tid * 16, in every step: its lane's DMA fetches
@@ -351,8 +359,8 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     auto conv_finish = [&](int j) {
         const int c0 = tile_c0(j);
         const int vcol = c0 + 8 * gc;
-        grad8_fix(csyk, csbk, cy - vcol, blank - vcol, padded ? c0 + kBK > V : c0 != j * kBK, padded ? 0 : j * kBK - vcol,
-                  padded ? V - vcol : 8, gx);
+        grad8_fix(csyk, csbk, cy - vcol, blank - vcol, padded ? c0 + kBK > V : c0 != (jt0 + j) * kBK,
+                  padded ? 0 : (jt0 + j) * kBK - vcol, padded ? V - vcol : 8, gx);
         *(lds_u128)(uintptr_t)(lds0 + kG0 + (j % kNG) * kGBytes + tid * 16) = DT::pack(gx);
     };
     f32x16 acc[2][4];
@@ -391,6 +399,20 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // nothing may land in LDS once it is reused below
 
+    if (vsplit > 1) {  // workgroup-uniform: fp32 sums of this share of the vocabulary, [workgroup][128 nodes][512]
+        float *out = split_partial + (size_t)blockIdx.x * kBM * kH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int n = (4 * wn + jn) * 32 + r;
+                    out[(size_t)row * kH + n] = acc[i][jn][e];
+                }
+        return;
+    }
     // ---- dH tile -> 16-bit, through LDS so that rows leave as whole 16-byte pieces ----
     constexpr int SP = kQRow + 16;  // staging pitch
     static_assert(kBM * SP <= kLdsBytesDh, "staging tile");
@@ -414,6 +436,23 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         if (row < wg_rows)
             *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(grad_hidden) + (size_t)(wg_row0 + row) * kQRow + ch * 16) = v;
     }
+}
+
+// dH rows of the row tiles whose vocabulary `vsplit` workgroups shared: their fp32 sums added in share order (a fixed
+// order: bitwise reproducible), rounded once.  One thread per four columns of a row.
+template <typename DT>
+__global__ __launch_bounds__(256) void rnnt_fused_bwd_dh_merge(const float *__restrict__ split_partial, int vsplit,
+                                                               long long row0, long long total_rows,
+                                                               typename DT::elem *__restrict__ grad_hidden) {
+    const long long row = row0 + (long long)blockIdx.x * 2 + (threadIdx.x >> 7);
+    if (row >= total_rows) return;
+    const int col = (threadIdx.x & 127) * 4;
+    const long long local = row - row0;
+    const float *p = split_partial + ((size_t)(local / kBM) * vsplit * kBM + (size_t)(local % kBM)) * kH + col;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < vsplit; ++i) s += *reinterpret_cast<const f32x4 *>(p + (size_t)i * kBM * kH);
+    typename DT::elem o[4] = {DT::from_float(s.x), DT::from_float(s.y), DT::from_float(s.z), DT::from_float(s.w)};
+    *reinterpret_cast<uint2 *>(grad_hidden + (size_t)row * kH + col) = *reinterpret_cast<const uint2 *>(o);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -626,7 +665,15 @@ struct DwPlan {
     int nchunks;          // node ranges
     int steps_per_chunk;  // steps of 64 nodes per range
     long long coef_rows;  // node records: the ranges' rows and the dH kernel's row tiles
+    // dH: one workgroup per CU at a time, so `row_tiles` take ceil(row_tiles / CUs) rounds and a last round with few
+    // tiles costs as much as a full one (config 2: 4100 tiles on 256 CUs = 16 rounds + 4 tiles, +6 %).  The surplus
+    // tiles (up to half a round) are launched apart, their vocabulary shared by as many workgroups as fill the round.
+    // Planned for the 256 CUs of an MI355X whatever the device (the workspace size must depend on the shape only).
+    long long dh_full;    // row tiles that walk the whole vocabulary
+    int dh_surplus;       // row tiles whose vocabulary is shared ...
+    int dh_vsplit;        // ... by this many workgroups each (1: no surplus launch)
 };
+constexpr int kPlanCUs = 256;
 DwPlan dw_plan(long long rows, int V) {
     DwPlan p;
     p.nvb = (V + kBM - 1) / kBM;
@@ -638,6 +685,20 @@ DwPlan dw_plan(long long rows, int V) {
     p.nchunks = (int)((steps + p.steps_per_chunk - 1) / p.steps_per_chunk);
     const long long a = (long long)p.nchunks * p.steps_per_chunk * kBK, b = (rows + kBM - 1) / kBM * kBM;
     p.coef_rows = a > b ? a : b;
+    const long long row_tiles = (rows + kBM - 1) / kBM;
+    const int nt = (V + kBK - 1) / kBK;
+    p.dh_full = row_tiles / kPlanCUs * kPlanCUs;
+    p.dh_surplus = (int)(row_tiles - p.dh_full);
+    p.dh_vsplit = 1;
+    if (p.dh_surplus > 0 && p.dh_surplus <= kPlanCUs / 2) {
+        p.dh_vsplit = kPlanCUs / p.dh_surplus;
+        if (p.dh_vsplit > nt / 2) p.dh_vsplit = nt / 2;  // at least two tiles per share
+    }
+    if (p.dh_vsplit < 2) {
+        p.dh_full = row_tiles;
+        p.dh_surplus = 0;
+        p.dh_vsplit = 1;
+    }
     return p;
 }
 inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
@@ -646,6 +707,7 @@ struct BwdWorkspace {
     NodeG *coefs;
     float *partial;
     float *pbias;
+    float *dh_partial;  // [dh_surplus * dh_vsplit][128][512] fp32
     size_t bytes;
 };
 BwdWorkspace carve_bwd(void *ws, const DwPlan &p) {
@@ -658,6 +720,8 @@ BwdWorkspace carve_bwd(void *ws, const DwPlan &p) {
     off += align256((size_t)p.nchunks * p.nvb * kBM * kH * sizeof(float));
     w.pbias = reinterpret_cast<float *>(c + off);
     off += align256((size_t)p.nchunks * p.nvb * kBM * sizeof(float));
+    w.dh_partial = reinterpret_cast<float *>(c + off);
+    off += align256((size_t)p.dh_surplus * p.dh_vsplit * kBM * kH * sizeof(float));
     w.bytes = off;
     return w;
 }
@@ -678,10 +742,21 @@ rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logi
     hipLaunchKernelGGL(rnnt_bwd_node_coefs, dim3((unsigned)((p.coef_rows + 255) / 256)), dim3(256), 0, st, w.coefs, labels,
                        act_lens, label_lens, L, grad_out, grad_out_stride, grad_scale, o.maxT, o.maxU, rows, p.coef_rows);
     if (o.stage_events && o.stage_events[1]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[1]), st);
-    if (grad_hidden)
-        hipLaunchKernelGGL((rnnt_fused_bwd_dh<DT>), dim3((unsigned)row_tiles), dim3(kThreads), 0, st,
-                           static_cast<const E *>(logits), static_cast<const E *>(weight), w.coefs,
-                           static_cast<E *>(grad_hidden), V, ldv, padded, o.blank_label, rows);
+    if (grad_hidden) {
+#define DH_LAUNCH(NWG, TILE0, SPLIT)                                                                              \
+    hipLaunchKernelGGL((rnnt_fused_bwd_dh<DT>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st,                      \
+                       static_cast<const E *>(logits), static_cast<const E *>(weight), w.coefs,                   \
+                       static_cast<E *>(grad_hidden), V, ldv, padded, o.blank_label, rows, (long long)(TILE0),    \
+                       (int)(SPLIT), w.dh_partial)
+        if (p.dh_full > 0) DH_LAUNCH(p.dh_full, 0, 1);
+        if (p.dh_surplus > 0) {
+            DH_LAUNCH((long long)p.dh_surplus * p.dh_vsplit, p.dh_full, p.dh_vsplit);
+            const long long row0 = p.dh_full * kBM, n = rows - row0;
+            hipLaunchKernelGGL((rnnt_fused_bwd_dh_merge<DT>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, w.dh_partial,
+                               p.dh_vsplit, row0, rows, static_cast<E *>(grad_hidden));
+        }
+#undef DH_LAUNCH
+    }
     if (o.stage_events && o.stage_events[2]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[2]), st);
     if (grad_weight || grad_bias) {
         hipLaunchKernelGGL((rnnt_fused_bwd_dw<DT>), dim3((unsigned)(p.nchunks * p.nvb)), dim3(kThreads), 0, st,
