@@ -305,6 +305,69 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const typename DT::elem
     if (lane == 0) logp[r] = (m - m) - __logf(sum);  // m - m: NaN for an infinite maximum, as x - max is in torch
 }
 
+// The same for rows that start on 16 bytes (x 16-byte aligned, V a multiple of the chunk's element count): 16-byte
+// loads and ONE pass — the running {max, sum 2^((x - max) log2e)} of rnnt_k1_lse beside the running argmax; the two
+// lanes' worth of state are merged with butterflies at the end.  Same results as the element-wise kernel above up to
+// the order of the fp32 additions.
+template <typename DT>
+__global__ __launch_bounds__(256) void row_argmax_vec_kernel(const typename DT::elem *__restrict__ x, int rows, int V,
+                                                             int *__restrict__ out, float *__restrict__ logp) {
+    constexpr int EPC = DT::EPC;
+    constexpr float kLog2eF = 1.4426950408889634f, kLn2F = 0.6931471805599453f;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (r >= rows) return;
+    const u32x4 *row4 = reinterpret_cast<const u32x4 *>(x + (size_t)r * V);
+    const int nchunks = V / EPC;
+    Best best = {-INFINITY, 0, 0x7fffffff};
+    float m = -INFINITY, s = 0.0f;  // over this lane's elements; NaN elements poison s, which is what the result wants
+    for (int c = lane; c < nchunks; c += kWave) {
+        float f[EPC];
+        DT::unpack(row4[c], f);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            const Best cand = {f[j] != f[j] ? INFINITY : f[j], f[j] != f[j] ? 1 : 0, c * EPC + j};
+            if (better(cand, best)) best = cand;
+            cm = fmaxf(cm, f[j]);
+        }
+        if (logp != nullptr) {
+            const float mn = fmaxf(m, cm);
+            if (mn != -INFINITY) {  // (all -inf so far: nothing to add, and -inf - -inf must not be formed)
+                float acc = (s == 0.0f) ? 0.0f : s * __builtin_amdgcn_exp2f((m - mn) * kLog2eF);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) acc += __builtin_amdgcn_exp2f((f[j] - mn) * kLog2eF);
+                s = acc;
+                m = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(best.v, off, kWave);
+        o.nan = __shfl_xor(best.nan, off, kWave);
+        o.i = __shfl_xor(best.i, off, kWave);
+        if (better(o, best)) best = o;
+    }
+    if (lane == 0) out[r] = best.i;
+    if (logp == nullptr) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float mo = __shfl_xor(m, off, kWave), so = __shfl_xor(s, off, kWave);
+        const float mn = fmaxf(m, mo);
+        const float a = (s == 0.0f || m == -INFINITY) ? 0.0f : s * __builtin_amdgcn_exp2f((m - mn) * kLog2eF);
+        const float b = (so == 0.0f || mo == -INFINITY) ? 0.0f : so * __builtin_amdgcn_exp2f((mo - mn) * kLog2eF);
+        // (both lanes of a pair add in the same order: the lower lane's share first)
+        s = (lane & off) ? b + a : a + b;
+        m = mn;
+    }
+    if (lane == 0) {
+        const float mm = best.nan ? __builtin_nanf("") : best.v;
+        logp[r] = (mm - mm) - kLn2F * __builtin_amdgcn_logf(s);  // mm - mm: NaN for an infinite maximum, as torch
+    }
+}
+
 inline int frame_chunks(int T) { return (T + kTC - 1) / kTC; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -419,20 +482,22 @@ rnntStatus_t rnnt_row_max_logp(const void *x, int rows, int V, rnntDtype_t dtype
     if (x == nullptr || out == nullptr || rows < 1 || V < 1) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((rows + 3) / 4), block(256);
+    // rows on 16 bytes: the one-pass kernel with 16-byte loads; any other layout: element by element
+#define ROW_LAUNCH(DT, E)                                                                                          \
+    do {                                                                                                          \
+        if (aligned16(x) && V % DT::EPC == 0)                                                                     \
+            hipLaunchKernelGGL((row_argmax_vec_kernel<DT>), grid, block, 0, st, static_cast<const E *>(x), rows, V, out, \
+                               logp);                                                                             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((row_argmax_kernel<DT>), grid, block, 0, st, static_cast<const E *>(x), rows, V, out, logp); \
+    } while (0)
     switch (dtype) {
-        case RNNT_DTYPE_F32:
-            hipLaunchKernelGGL((row_argmax_kernel<F32>), grid, block, 0, st, static_cast<const float *>(x), rows, V, out, logp);
-            break;
-        case RNNT_DTYPE_BF16:
-            hipLaunchKernelGGL((row_argmax_kernel<BF16>), grid, block, 0, st, static_cast<const __bf16 *>(x), rows, V,
-                               out, logp);
-            break;
-        case RNNT_DTYPE_F16:
-            hipLaunchKernelGGL((row_argmax_kernel<F16>), grid, block, 0, st, static_cast<const _Float16 *>(x), rows, V,
-                               out, logp);
-            break;
+        case RNNT_DTYPE_F32: ROW_LAUNCH(F32, float); break;
+        case RNNT_DTYPE_BF16: ROW_LAUNCH(BF16, __bf16); break;
+        case RNNT_DTYPE_F16: ROW_LAUNCH(F16, _Float16); break;
         default: return RNNT_STATUS_INVALID_VALUE;
     }
+#undef ROW_LAUNCH
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 
