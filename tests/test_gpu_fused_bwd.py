@@ -191,6 +191,29 @@ def test_fused_backward_on_padded_rows(B, T, U, V, ld, dtype, what):
         assert torch.equal(dh, dh2) and torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+def test_fused_backward_random_shapes():
+    """24 seeded random shapes (lattice 1 ... ~25 000 nodes: the shared-vocabulary launch of small and surplus row tiles
+    and the plain one; vocabularies on both sides of every tile boundary; contiguous, padded and merely 16-byte-aligned
+    rows).  A one-off run of the same loop over 240 further shapes passed on the round-3 build."""
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        B = int(rng.integers(1, 7))
+        T = int(rng.integers(1, 200))
+        U = int(rng.integers(0, 24))
+        V = int(rng.choice([128, 129, 136, 255, 257, 520, 1027, 2048, 4234, int(rng.integers(128, 3000))]))
+        dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float16
+        padded = (V + 127) // 128 * 128
+        ld = int(rng.choice([padded, padded + 128, V if V % 8 == 0 else padded, max((V + 7) // 8 * 8, padded if V % 8 else 0)]))
+        hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, 512, dtype, seed=500 + it)
+        st, logits, _, ws = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=ld)
+        assert st == 0, (B, T, U, V, ld)
+        go = rng.uniform(0.2, 1.5, B).astype(np.float32)
+        g = k3_c_abi(logits[..., :V].contiguous(), labels, al, ll, ws, go, 1, 1.0)
+        st, dh, dw, db = backward_c_abi(hidden, weight, logits, labels, al, ll, ws, go, 1, 1.0, ld=ld)
+        assert st == 0, (B, T, U, V, ld)
+        check_against_k3(hidden, weight, g, dh, dw, db)
+
+
 def test_fused_backward_stride_checks():
     hidden, weight, bias, labels, al, ll = make_inputs(1, 4, 2, 4234, 512, torch.bfloat16, seed=1)
     st, logits, _, ws = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=4352)
