@@ -99,6 +99,43 @@ class JointNet(nn.Module):
             nn.Linear(inner_dim, vocab_size, bias=True),
         )
 
+    def hidden(self, enc_state, dec_state):
+        """``[B, T, U+1, inner_dim]``: what the reference's ``mlp[:2]`` (Linear + Tanh) returns on the repeated and
+        concatenated (or summed) states (model.py:46-58), from ``enc_state`` ``[B, T, He]`` and ``dec_state``
+        ``[B, U+1, Hd]`` without building the ``[B, T, U+1, He+Hd]`` tensor."""
+        first = self.mlp[0]
+        if self.joint == "concat":
+            he = enc_state.size(-1)
+            if he + dec_state.size(-1) != first.in_features:
+                raise RuntimeError("enc/dec state sizes do not add up to the joint's input_size")
+            w_enc, w_dec = first.weight[:, :he], first.weight[:, he:]
+        else:
+            w_enc = w_dec = first.weight
+        enc_proj = F.linear(enc_state, w_enc, first.bias)      # [B, T, H]
+        dec_proj = F.linear(dec_state, w_dec)                  # [B, U+1, H]
+        return joint_hidden(enc_proj, dec_proj)
+
+    def transducer_loss(self, enc_state, dec_state, labels, act_lens, label_lens, blank=0, reduction="mean"):
+        """The reference's two lines ``logits = self.joint(enc_state, dec_state)`` and
+        ``self.transducer_loss(logits, tokens.int(), output_length, tokens_length.int())`` (model.py:115-116) as one
+        call.  16-bit states (bf16/fp16 training): the output projection and the loss run fused
+        (``rnnt_amd.FusedJointLoss``: the logits are written once and never read by a softmax pass, their gradient is
+        never written); fp32 states: the projection as a library GEMM and ``rnnt_amd.rnnt_loss`` on its logits."""
+        if enc_state.dim() != 3 or dec_state.dim() != 3:
+            raise ValueError("transducer_loss takes enc_state [B, T, He] and dec_state [B, U+1, Hd]")
+        if self.joint not in ("sum", "concat"):
+            raise NotImplementedError
+        hidden = self.hidden(enc_state, dec_state)
+        out = self.mlp[2]
+        if hidden.dtype in (torch.bfloat16, torch.float16):
+            from .fused import SUPPORTED_HIDDEN, fused_joint_loss
+
+            if hidden.size(-1) in SUPPORTED_HIDDEN and out.out_features >= 64 and out.bias is not None:
+                return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction)
+        from .loss import rnnt_loss
+
+        return rnnt_loss(out(hidden), labels, act_lens, label_lens, blank=blank, reduction=reduction)
+
     def forward(self, enc_state, dec_state, softmax=False):
         if enc_state.dim() != dec_state.dim():
             raise ValueError("input_TN and input_PN must be have same size."
@@ -109,17 +146,7 @@ class JointNet(nn.Module):
             # already unsqueezed by the caller ([B,T,1,He] / [B,1,U+1,Hd]), model.py:46-50
             enc_state, dec_state = enc_state.squeeze(2), dec_state.squeeze(1)
         if enc_state.dim() == 3:
-            first, out = self.mlp[0], self.mlp[2]
-            if self.joint == "concat":
-                he = enc_state.size(-1)
-                if he + dec_state.size(-1) != first.in_features:
-                    raise RuntimeError("enc/dec state sizes do not add up to the joint's input_size")
-                w_enc, w_dec = first.weight[:, :he], first.weight[:, he:]
-            else:
-                w_enc = w_dec = first.weight
-            enc_proj = F.linear(enc_state, w_enc, first.bias)      # [B, T, H]
-            dec_proj = F.linear(dec_state, w_dec)                  # [B, U+1, H]
-            joint = out(joint_hidden(enc_proj, dec_proj))          # [B, T, U+1, V]
+            joint = self.mlp[2](self.hidden(enc_state, dec_state))     # [B, T, U+1, V]
         else:
             # evaluation: one frame against one decoder state ([B *] H), model.py:51-54 — a few hundred
             # numbers; greedy/beam decoding is outside this package's scope

@@ -172,6 +172,62 @@ def test_joint_then_loss_end_to_end_against_oracles():
         assert rel_to_max(p.grad.cpu(), q.grad) <= 1e-4
 
 
+def test_jointnet_transducer_loss_is_the_two_reference_lines_in_one_call():
+    """JointNet.transducer_loss(enc, dec, tokens, out_len, tok_len) = model.py:115-116 in one call.  fp32: the same
+    kernels as the two calls, so the same bits.  bf16 at the reference's sizes (He = Hd = 320, inner 512, V = 4232): the
+    fused projection + loss forward and backward; the loss against the C loss oracle run on the float64 joint of the
+    same rounded parameters (measured 5e-6 relative: the bf16 roundings of hidden and logits average out over the path; bar
+    1e-4), every gradient against float64 autograd through that joint and the oracle's gradient, within 2 % of the
+    tensor's largest entry (measured 0.03-1.0 %: hidden and logits are rounded to bf16 on the way)."""
+    import rnnt_amd
+
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    # fp32, small: identical to RNNTLoss()(net(enc, dec), ...)
+    B, T, U, He, Hd, H, V = 2, 9, 3, 16, 8, 32, 70
+    net = rnnt_amd.JointNet(He + Hd, H, V).to(DEV)
+    enc, dec = torch.randn(B, T, He, device=DEV), torch.randn(B, U + 1, Hd, device=DEV)
+    labels = torch.from_numpy(rng.integers(1, V, size=(B, U)).astype(np.int32)).to(DEV)
+    al = torch.tensor([T, 6], dtype=torch.int32, device=DEV)
+    ll = torch.tensor([U, 1], dtype=torch.int32, device=DEV)
+    e1, d1 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    l1 = net.transducer_loss(e1, d1, labels, al, ll)
+    l1.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    e2, d2 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    l2 = rnnt_amd.RNNTLoss()(net(e2, d2), labels, al, ll)
+    l2.backward()
+    assert torch.equal(l1, l2) and torch.equal(e1.grad, e2.grad) and torch.equal(d1.grad, d2.grad)
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, net.parameters()))
+
+    # bf16, the reference's layer sizes: the fused path
+    B, T, U, He, Hd, H, V = 3, 150, 12, 320, 320, 512, 4232
+    net = rnnt_amd.JointNet(He + Hd, H, V).to(DEV).to(torch.bfloat16)
+    enc = torch.randn(B, T, He, device=DEV).to(torch.bfloat16)
+    dec = torch.randn(B, U + 1, Hd, device=DEV).to(torch.bfloat16)
+    lab = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    aln, lln = np.array([T, 97, 140], np.int32), np.array([U, 5, 12], np.int32)
+    e, d = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    loss = net.transducer_loss(e, d, torch.from_numpy(lab).to(DEV), torch.from_numpy(aln).to(DEV),
+                               torch.from_numpy(lln).to(DEV))
+    loss.backward()
+    # float64 reference of the same rounded parameters and inputs
+    params = [p.detach().double().cpu().requires_grad_(True) for p in net.parameters()]
+    e64, d64 = enc.double().cpu().requires_grad_(True), dec.double().cpu().requires_grad_(True)
+    logits = joint_logits(e64, d64, *params)
+    c, g, _ = oracle.rnnt_loss_c(logits.detach().numpy(), lab, aln, lln, dtype=np.float64)
+    logits.backward(torch.from_numpy(g / B))
+    assert abs(loss.item() - c.sum() / B) <= 1e-4 * abs(c.sum() / B)
+    assert rel_to_max(e.grad.double().cpu(), e64.grad) <= 0.02
+    assert rel_to_max(d.grad.double().cpu(), d64.grad) <= 0.02
+    for p, q in zip(net.parameters(), params):
+        assert rel_to_max(p.grad.double().cpu(), q.grad) <= 0.02
+    with pytest.raises(ValueError):
+        net.transducer_loss(enc[0], dec[0], torch.from_numpy(lab).to(DEV), torch.from_numpy(aln).to(DEV),
+                            torch.from_numpy(lln).to(DEV))
+
+
 def test_joint_hidden_config2_size():
     """B32 T400 U40 H512 (the reference's joint at BASELINE config 2): 268 M outputs, checked against
     the same expression evaluated by torch on the device, and the reductions against torch sums."""
