@@ -228,6 +228,29 @@ def test_jointnet_transducer_loss_is_the_two_reference_lines_in_one_call():
                             torch.from_numpy(lln).to(DEV))
 
 
+def test_jointnet_transducer_loss_never_waits_on_the_host():
+    """The one-call joint + loss (fused path) and its backward enqueue work only: no host synchronisation."""
+    import rnnt_amd
+
+    torch.manual_seed(5)
+    B, T, U, He, Hd, H, V = 2, 120, 9, 64, 32, 512, 1000
+    net = rnnt_amd.JointNet(He + Hd, H, V).to(DEV).to(torch.bfloat16)
+    enc = torch.randn(B, T, He, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    dec = torch.randn(B, U + 1, Hd, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    labels = torch.randint(1, V, (B, U), device=DEV, dtype=torch.int32)
+    al = torch.tensor([T, 77], dtype=torch.int32, device=DEV)
+    ll = torch.tensor([U, 4], dtype=torch.int32, device=DEV)
+    net.transducer_loss(enc, dec, labels, al, ll).backward()      # (first call: library load, allocator warm-up)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = net.transducer_loss(enc, dec, labels, al, ll)
+        loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bool(torch.isfinite(loss).all()) and bool(torch.isfinite(enc.grad.float()).all())
+
+
 def test_joint_hidden_config2_size():
     """B32 T400 U40 H512 (the reference's joint at BASELINE config 2): 268 M outputs, checked against
     the same expression evaluated by torch on the device, and the reductions against torch sums."""
