@@ -59,5 +59,20 @@ def test_single_rank_rccl_equals_unsharded_bitwise():
         a4 = d(acts).requires_grad_(True)
         rnnt_amd.RNNTLoss(reduction="mean")(a4, d(labels), d(al), d(ll)).backward()
         assert torch.equal(a3.grad, a4.grad)
+        # the fused projection + loss under the same harness: loss_fn receives the shard's hidden activations
+        torch.manual_seed(2)
+        H, V = 512, 520
+        proj = torch.nn.Linear(H, V).to(dev).to(torch.bfloat16)
+        hidden = torch.tanh(torch.randn(5, 20, 8, H, device=dev)).to(torch.bfloat16)
+        fused_costs = lambda h, lab, tl, ul, blank: rnnt_amd.fused_joint_loss(
+            h, proj.weight, proj.bias, lab, tl, ul, blank=blank, reduction="none", min_nodes=0)
+        h1, h2 = hidden.clone().requires_grad_(True), hidden.clone().requires_grad_(True)
+        l1 = rnnt_amd.FusedJointLoss(min_nodes=0)(h1, proj, d(labels), d(al), d(ll))
+        l1.backward()
+        gw = proj.weight.grad.clone()
+        proj.zero_grad()
+        l2 = rnnt_amd.ShardedRNNTLoss(reduction="mean", loss_fn=fused_costs)(h2, d(labels), d(al), d(ll), global_batch=5)
+        l2.backward()
+        assert torch.equal(l1, l2) and torch.equal(h1.grad, h2.grad) and torch.equal(gw, proj.weight.grad)
     finally:
         dist.destroy_process_group()
