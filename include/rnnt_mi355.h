@@ -259,6 +259,45 @@ rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *we
                                               const void *workspace, void *backward_workspace, rnntOptions options);
 
 /*
+ * The pair above in the COMPACTED node order: for ragged batches.  The reference's joint computes all B * maxT * U1
+ * rows of the logits (/root/reference/src/rnnt/model.py:46-59) and its loss then ignores the rows outside the
+ * utterances' lattices (t >= act_lens[b] or u > label_lens[b]); with the projection and the loss in one call nothing
+ * outside the lattices has to exist.  These calls walk the nodes INSIDE the lattices only — utterance by utterance,
+ * frame by frame, label position fastest, numbered on the device from the two length tensors (the host never reads
+ * them) — and keep the logits in that order: row k of `logits` belongs to the k-th node, not to row k of the
+ * [B, maxT, U1] tensor.  Matrix work, logits memory and HBM traffic then follow the sum of T_b (U_b + 1), not
+ * B maxT U1 (a batch cut like BASELINE config 3 has 35 % of its rows inside lattices).  hidden and grad_hidden stay
+ * [B, maxT, U1, H]: the kernels gather the nodes' hidden vectors and scatter their gradients; the rows of grad_hidden
+ * that are no node are set to zero, hidden's are never read.
+ *   logits_rows        rows the logits buffer holds (logits_rows * logits_row_stride elements): an upper bound of the
+ *                      number of nodes known on the host; minibatch * maxT * maxU always suffices.  The grids are cut
+ *                      for it, workgroups past the last node leave at once.  Should the lattices hold MORE nodes, the
+ *                      surplus nodes are not computed: the costs of their utterances come out NaN.
+ *   compact_workspace  rnnt_joint_loss_compact_workspace_size bytes, 256-byte aligned: the node -> row map, written
+ *                      by the forward call, read by the backward call (with the lattice workspace).
+ *   backward_workspace rnnt_joint_loss_backward_compact_workspace_size(hidden_size, alphabet_size, logits_rows) bytes.
+ * Everything else as rnnt_joint_loss_forward_strided / rnnt_joint_loss_backward_strided, whose results these calls
+ * reproduce on a batch without padding; minibatch * maxT * maxU must fit 31 bits.  Utterances whose lengths do not
+ * fit the tensor have no nodes (NaN cost, zero gradient, as everywhere in this library).
+ */
+rnntStatus_t rnnt_joint_loss_compact_workspace_size(int minibatch, int maxT, int maxU, size_t *size_bytes);
+rnntStatus_t rnnt_joint_loss_forward_compact(const void *hidden, const void *weight, const float *bias,
+                                             void *logits_out, int logits_row_stride, long long logits_rows,
+                                             const int *labels, const int *act_lens, const int *label_lens,
+                                             int hidden_size, int alphabet_size, int minibatch, float *costs,
+                                             float *loss_out, int reduction, void *workspace, void *compact_workspace,
+                                             rnntOptions options);
+rnntStatus_t rnnt_joint_loss_backward_compact_workspace_size(int hidden_size, int alphabet_size, long long logits_rows,
+                                                             size_t *size_bytes);
+rnntStatus_t rnnt_joint_loss_backward_compact(const void *hidden, const void *weight, const void *logits,
+                                              int logits_row_stride, long long logits_rows, const int *labels,
+                                              const int *act_lens, const int *label_lens, int hidden_size,
+                                              int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
+                                              float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
+                                              const void *workspace, const void *compact_workspace,
+                                              void *backward_workspace, rnntOptions options);
+
+/*
  * ---- greedy decoding --------------------------------------------------------
  * out[r] = first index of the maximum of row r of x[rows, V] (a NaN counts as the maximum: torch.argmax's
  * conventions).  Replaces the per-frame softmax -> argmax of the reference's greedy loop

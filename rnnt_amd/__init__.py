@@ -15,9 +15,9 @@ from .joint import JointNet, joint_hidden  # noqa: F401
 from .parallel import (ShardedRNNTLoss, all_reduce_gradients, balanced_assignment, shard_bounds,  # noqa: F401
                        shard_batch)
 from .train_step import GuardedStep  # noqa: F401
-from .fused import FusedJointLoss, fused_joint_loss  # noqa: F401
+from .fused import FusedJointLoss, count_lattice_nodes, fused_joint_loss  # noqa: F401
 
 __all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch",
            "balanced_assignment", "all_reduce_gradients", "JointNet", "joint_hidden", "greedy_decode", "greedy_search_batch", "row_argmax",
-           "row_max_logp", "GuardedStep", "FusedJointLoss", "fused_joint_loss", "set_binding", "get_binding"]
+           "row_max_logp", "GuardedStep", "FusedJointLoss", "fused_joint_loss", "count_lattice_nodes", "set_binding", "get_binding"]
 __version__ = "0.2.0"

@@ -42,6 +42,10 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_loss_backward_workspace_size",
     "rnnt_joint_loss_backward",
     "rnnt_joint_loss_backward_strided",
+    "rnnt_joint_loss_compact_workspace_size",
+    "rnnt_joint_loss_forward_compact",
+    "rnnt_joint_loss_backward_compact_workspace_size",
+    "rnnt_joint_loss_backward_compact",
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
@@ -138,6 +142,19 @@ def load() -> ctypes.CDLL:
                                                          ctypes.c_int, fp, ctypes.c_int, ctypes.c_float, vp, vp, fp, vp, vp,
                                                          RnntOptions]
         lib.rnnt_joint_loss_backward_strided.restype = ctypes.c_int
+        lib.rnnt_joint_loss_compact_workspace_size.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_size_t)]
+        lib.rnnt_joint_loss_compact_workspace_size.restype = ctypes.c_int
+        lib.rnnt_joint_loss_forward_compact.argtypes = [vp, vp, fp, vp, ctypes.c_int, ctypes.c_longlong, ip, ip, ip,
+                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, ctypes.c_int,
+                                                        vp, vp, RnntOptions]
+        lib.rnnt_joint_loss_forward_compact.restype = ctypes.c_int
+        lib.rnnt_joint_loss_backward_compact_workspace_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
+                                                                        ctypes.POINTER(ctypes.c_size_t)]
+        lib.rnnt_joint_loss_backward_compact_workspace_size.restype = ctypes.c_int
+        lib.rnnt_joint_loss_backward_compact.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_longlong, ip, ip, ip,
+                                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int,
+                                                         ctypes.c_float, vp, vp, fp, vp, vp, vp, RnntOptions]
+        lib.rnnt_joint_loss_backward_compact.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_joint_hidden_forward.restype = ctypes.c_int

@@ -60,8 +60,10 @@ constexpr int kNQ = 3;                 // Q ring: the tile being multiplied, the
 constexpr int kGBytes = kBM * kBK * 2; // 8 KiB: one 1-KiB LDS-DMA piece per wave
 constexpr int kNG = 5;                 // gradient-tile ring: multiplied / converted in place / landed / two in flight
 constexpr int kCBytes = kWaves * 256;  // dW: node records of one step, 256 bytes per wave
+constexpr int kNC = 7;                 // dW: ring of node records: they land three steps before their tile is converted,
+                                       // one step before the hidden rows they name are fetched
 constexpr int kQ0 = 0, kG0 = kNQ * kQBytes, kC0 = kG0 + kNG * kGBytes;
-constexpr int kLdsBytesDh = kC0, kLdsBytesDw = kC0 + kNG * kCBytes;  // 136 KiB, 146 KiB
+constexpr int kLdsBytesDh = kC0, kLdsBytesDw = kC0 + kNC * kCBytes;  // 136 KiB, 150 KiB
 constexpr int kDmaPerStep = kBK / kWaves;  // Q rows per wave and step
 
 // What K3 derives per lattice node (NodeCoef of lattice.h) in the form the tile prologue uses.
@@ -70,7 +72,9 @@ struct __attribute__((aligned(32))) NodeG {
     float sbk;
     int y;                  // label of the node's emit arc, -1 if none, kPadding for a padding node (t >= T_b or
                             // u > U_b, or lengths that do not fit): g = 0 there whatever the logits hold
-    int pad[2];
+    int row;                // the node's row of the [B, maxT, U1] tensor: where its hidden vector is (the records are
+                            // in the order the logits are stored in, lattice.h: Compact); 0 for a padding record
+    int pad;
 };
 constexpr int kPadding = -2;
 
@@ -78,13 +82,15 @@ __global__ __launch_bounds__(256) void rnnt_bwd_node_coefs(NodeG *__restrict__ o
                                                            const int *__restrict__ act_lens,
                                                            const int *__restrict__ label_lens, Lattice L,
                                                            const float *__restrict__ grad_out, int grad_out_stride,
-                                                           float grad_scale, int maxT, int U1, long long total_rows,
-                                                           long long padded_rows) {
+                                                           float grad_scale, int maxT, int U1, long long row_cap,
+                                                           long long padded_rows, Compact cmap) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= padded_rows) return;
-    NodeG g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, kPadding, {0, 0}};
-    if (r < total_rows) {
-        const RowCoord c = decode_row(r, maxT, U1);
+    NodeG g = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, kPadding, 0, 0};
+    if (r < compact_total(cmap, row_cap)) {  // (rows are lattice nodes in the order the logits are stored in: lattice.h)
+        const long long row = compact_row(cmap, r);
+        const RowCoord c = decode_row(row, maxT, U1);
+        g.row = (int)row;
         const int Tb = act_lens[c.b];
         const int Ub = label_lens[c.b];
         if (lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub) {
@@ -264,8 +270,8 @@ template <typename DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ weight,
                        const NodeG *__restrict__ coefs, typename DT::elem *__restrict__ grad_hidden, int V, int ldv,
-                       int padded, int blank, long long total_rows, long long row_tile0, int vsplit,
-                       float *__restrict__ split_partial) {
+                       int padded, int blank, long long row_cap, long long row_tile0, int vsplit,
+                       float *__restrict__ split_partial, Compact cmap) {
     typedef typename DT::elem E;
     typedef typename Mma<DT>::frag frag;
     typedef Waits<1> W;
@@ -282,6 +288,10 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
     // each walks 1/S of the vocabulary tiles and leaves its fp32 sums in `split_partial` for rnnt_fused_bwd_dh_merge.
     const long long wg_row0 = (row_tile0 + blockIdx.x / vsplit) * kBM;
     const int split = blockIdx.x % vsplit;
+    // rows = lattice nodes in the order the logits are stored in (lattice.h: Compact); the grid is cut for row_cap rows
+    // and the workgroups past the last node leave at once
+    const long long total_rows = compact_total(cmap, row_cap);
+    if (wg_row0 >= total_rows) return;  // workgroup-uniform, before the first barrier
     const int wg_rows = (int)(total_rows - wg_row0 < kBM ? total_rows - wg_row0 : kBM);
     const int NT_all = (V + kBK - 1) / kBK;
     const int jt0 = (int)((long long)split * NT_all / vsplit);                 // first vocabulary tile of this workgroup
@@ -433,8 +443,9 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
         const int id = tid + kThreads * k;
         const int row = id / (kQRow / 16), ch = id % (kQRow / 16);
         const u32x4 v = *(lds_cu128)(uintptr_t)(lds0 + row * SP + ch * 16);
-        if (row < wg_rows)
-            *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(grad_hidden) + (size_t)(wg_row0 + row) * kQRow + ch * 16) = v;
+        if (row < wg_rows)  // (grad_hidden is [B, maxT, U1, H] whatever the order of the nodes)
+            *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(grad_hidden) +
+                                       (size_t)compact_row(cmap, wg_row0 + row) * kQRow + ch * 16) = v;
     }
 }
 
@@ -442,17 +453,42 @@ void rnnt_fused_bwd_dh(const typename DT::elem *__restrict__ logits, const typen
 // order: bitwise reproducible), rounded once.  One thread per four columns of a row.
 template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_fused_bwd_dh_merge(const float *__restrict__ split_partial, int vsplit,
-                                                               long long row0, long long total_rows,
-                                                               typename DT::elem *__restrict__ grad_hidden) {
+                                                               long long row0, long long row_cap,
+                                                               typename DT::elem *__restrict__ grad_hidden, Compact cmap) {
     const long long row = row0 + (long long)blockIdx.x * 2 + (threadIdx.x >> 7);
-    if (row >= total_rows) return;
+    if (row >= compact_total(cmap, row_cap)) return;
     const int col = (threadIdx.x & 127) * 4;
     const long long local = row - row0;
     const float *p = split_partial + ((size_t)(local / kBM) * vsplit * kBM + (size_t)(local % kBM)) * kH + col;
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < vsplit; ++i) s += *reinterpret_cast<const f32x4 *>(p + (size_t)i * kBM * kH);
     typename DT::elem o[4] = {DT::from_float(s.x), DT::from_float(s.y), DT::from_float(s.z), DT::from_float(s.w)};
-    *reinterpret_cast<uint2 *>(grad_hidden + (size_t)row * kH + col) = *reinterpret_cast<const uint2 *>(o);
+    *reinterpret_cast<uint2 *>(grad_hidden + (size_t)compact_row(cmap, row) * kH + col) = *reinterpret_cast<const uint2 *>(o);
+}
+
+// Compacted order: the rows of grad_hidden [B, maxT, U1, H] that are no lattice node (padding, or a node past the
+// capacity of the logits buffer) are written by no workgroup of rnnt_fused_bwd_dh: zeros from here.  One thread looks
+// one row of the tensor up; the wave then writes the rows that need it, one KiB per instruction (16 bytes per lane),
+// so a batch without padding costs the lookups only.
+template <typename DT>
+__global__ __launch_bounds__(256) void rnnt_fused_bwd_zero_padding(typename DT::elem *__restrict__ grad_hidden,
+                                                                   const NodeSpan *__restrict__ spans, int maxT, int U1,
+                                                                   long long rows, long long row_cap) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool zero = false;
+    if (r < rows) {
+        const RowCoord c = decode_row(r, maxT, U1);
+        const NodeSpan s = spans[c.b];
+        zero = !(c.t < s.Tb && c.u < s.Ub1 && s.first + (long long)c.t * s.Ub1 + c.u < row_cap);
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    unsigned long long todo = __ballot(zero);
+    char *wave_row0 = reinterpret_cast<char *>(grad_hidden) + (size_t)(r - lane) * kQRow;
+    while (todo) {  // wave-uniform
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        *reinterpret_cast<u32x4 *>(wave_row0 + (size_t)k * kQRow + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -462,8 +498,8 @@ template <typename DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typename DT::elem *__restrict__ hidden,
                        const NodeG *__restrict__ coefs, float *__restrict__ partial, float *__restrict__ pbias, int V,
-                       int ldv, int padded, int blank, long long total_rows, long long coef_rows, int nvb,
-                       int steps_per_chunk) {
+                       int ldv, int padded, int blank, long long row_cap, long long coef_rows, int nvb,
+                       int steps_per_chunk, Compact cmap) {
     typedef typename Mma<DT>::frag frag;
     typedef Waits<2> W;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytesDw];
@@ -481,6 +517,15 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     // last tile of rnnt_fused_bwd_dh)
     const int vb0 = padded ? vmin : min(vmin, V - kBM);
     const bool masked = padded ? vmin + kBM > V : vb0 != vmin;
+    // rows = lattice nodes in the order the logits are stored in.  Compacted order (lattice.h): the host cut the
+    // node ranges for row_cap rows without knowing how many nodes the lattices hold; the ranges are re-cut here from
+    // the count on the device, so that every workgroup gets an equal share of the nodes that exist.
+    const long long total_rows = compact_total(cmap, row_cap);
+    if (cmap.rowmap) {
+        const long long steps = (total_rows + kBK - 1) / kBK;
+        const int nchunks = (int)(gridDim.x / nvb);
+        steps_per_chunk = (int)((steps + nchunks - 1) / nchunks);  // (<= the host's: total_rows <= row_cap)
+    }
     const long long row_begin = (long long)rc * steps_per_chunk * kBK;
     const long long rows_here = total_rows - row_begin;
     const int nsteps = rows_here <= 0 ? 0 : (int)min((long long)steps_per_chunk, (rows_here + kBK - 1) / kBK);
@@ -493,40 +538,55 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     const int vcol = vb0 + 8 * gc;
     const int db = blank - vcol, keep_from = padded ? 0 : vmin - vcol, keep_until = padded ? V - vcol : 8;
 
-    // step j's DMAs, k = 0 .. 3: hidden row k of this wave's four of step j + 2; k = 4: logits, k = 5: node records of
-    // step j + 4
+    // step j's DMAs, k = 0 .. 3: hidden row k of this wave's four of step j + 2; k = 4: logits of step j + 4; k = 5: node
+    // records of step j + 6.  The hidden vector of a node is row NodeG::row of `hidden` (the nodes are walked in the order
+    // the logits are stored in, which in the compacted order is not the tensor's): hrow[k] holds those rows for the Q
+    // tile this step fetches, wave-uniform, read from the records in LDS one step earlier (read_rows / take_rows).
+    int hrow[kDmaPerStep];
     auto issue = [&](int j, int k) {
         if (k < kDmaPerStep) {
             if (j + 2 >= 0) {
-                const long long row0 = row_begin + (long long)(j + 2 < nsteps ? j + 2 : 0) * kBK;
                 const int kr = wave * kDmaPerStep + k;
-                const long long row = row0 + kr < total_rows ? row0 + kr : total_rows - 1;  // (times g = 0)
+#ifdef FUSED_BWD_ABLATE_LOAD  // (timing build without the records: rows by arithmetic)
+                const long long row0 = row_begin + (long long)(j + 2 < nsteps ? j + 2 : 0) * kBK;
+                hrow[k] = (int)(row0 + kr < total_rows ? row0 + kr : total_rows - 1);
+#endif
 #ifndef FUSED_BWD_ABLATE_DMA
-                lds_dma16(dma_voff(lane, k & 3), reinterpret_cast<const char *>(hidden) + (size_t)row * kQRow,
+                lds_dma16(dma_voff(lane, k & 3), reinterpret_cast<const char *>(hidden) + (size_t)(unsigned)hrow[k] * kQRow,
                           lds0 + kQ0 + ((j + 2) % kNQ) * kQBytes + kr * kQRow);
 #endif
             }
-        } else {
-            const long long row0 = row_begin + (long long)(j + 4 < nsteps ? j + 4 : 0) * kBK;
-            const unsigned slot = (unsigned)((j + 4) % kNG);
+        } else if (k == kDmaPerStep) {
 #ifndef FUSED_BWD_ABLATE_LOAD
-            if (k == kDmaPerStep) {
-                // logits: this wave's piece = nodes 4 wave .. 4 wave + 3 of the step (past the end: the last node, ignored)
-                long long lrow = row0 + gr;
-                lrow = lrow < total_rows ? lrow : total_rows - 1;
-                const long long wrow0 = row0 + 4 * wave < total_rows ? row0 + 4 * wave : total_rows - 1;  // wave-uniform
-                const unsigned voff = (unsigned)(((lrow - wrow0) * ldv + vcol) * 2);  // 0 .. 3 rows on, this lane's chunk
-                lds_dma16(voff, reinterpret_cast<const char *>(logits) + (size_t)wrow0 * ldv * 2,
-                          lds0 + kG0 + slot * kGBytes + wave * 1024);
-            } else {
-                // node records of the same four nodes: 128 bytes, fetched by lanes 0-31 (and again by lanes 32-63)
-                long long crow0 = row0 + 4 * wave;
-                crow0 = crow0 + 4 <= coef_rows ? crow0 : coef_rows - 4;
-                lds_dma4((unsigned)((lane & 31) * 4), reinterpret_cast<const char *>(coefs + crow0),
-                         lds0 + kC0 + slot * kCBytes + wave * 256);
-            }
+            // logits: this wave's piece = nodes 4 wave .. 4 wave + 3 of the step (past the end: the last node, ignored)
+            const long long row0 = row_begin + (long long)(j + 4 < nsteps ? j + 4 : 0) * kBK;
+            long long lrow = row0 + gr;
+            lrow = lrow < total_rows ? lrow : total_rows - 1;
+            const long long wrow0 = row0 + 4 * wave < total_rows ? row0 + 4 * wave : total_rows - 1;  // wave-uniform
+            const unsigned voff = (unsigned)(((lrow - wrow0) * ldv + vcol) * 2);  // 0 .. 3 rows on, this lane's chunk
+            lds_dma16(voff, reinterpret_cast<const char *>(logits) + (size_t)wrow0 * ldv * 2,
+                      lds0 + kG0 + (unsigned)((j + 4) % kNG) * kGBytes + wave * 1024);
+#endif
+        } else {
+#ifndef FUSED_BWD_ABLATE_LOAD
+            // node records of this wave's four nodes: 128 bytes, fetched by lanes 0-31 (and again by lanes 32-63); past the
+            // end of the range: the range's first records again (valid rows, never converted)
+            const long long row0 = row_begin + (long long)(j + 6 < nsteps ? j + 6 : 0) * kBK;
+            long long crow0 = row0 + 4 * wave;
+            crow0 = crow0 + 4 <= coef_rows ? crow0 : coef_rows - 4;
+            lds_dma4((unsigned)((lane & 31) * 4), reinterpret_cast<const char *>(coefs + crow0),
+                     lds0 + kC0 + (unsigned)((j + 6) % kNC) * kCBytes + wave * 256);
 #endif
         }
+    };
+    // lane k < 4: NodeG::row of node 4 wave + k of tile t, from the records in LDS (landed and behind a barrier)
+    auto read_rows = [&](int t) {
+        return *(const __attribute__((address_space(3))) int *)(uintptr_t)(lds0 + kC0 + (unsigned)(t % kNC) * kCBytes +
+                                                                           wave * 256 + (lane & 3) * 32 + 24);
+    };
+    auto take_rows = [&](int v) {
+#pragma unroll
+        for (int k = 0; k < kDmaPerStep; ++k) hrow[k] = __builtin_amdgcn_readlane(v, k);
     };
     float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this thread's share of the bias gradient
     float gx[8];
@@ -534,7 +594,7 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
     int fdy;
     auto conv_main = [&](int j) {
         const unsigned slot = (unsigned)(j % kNG);
-        const unsigned ca = lds0 + kC0 + slot * kCBytes + wave * 256 + (lane >> 4) * 32;
+        const unsigned ca = lds0 + kC0 + (unsigned)(j % kNC) * kCBytes + wave * 256 + (lane >> 4) * 32;
         const u32x4 c0 = *(lds_cu128)(uintptr_t)ca;
         const u32x2 c1 = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)(ca + 16);
         u32x4 raw = *(lds_cu128)(uintptr_t)(lds0 + kG0 + slot * kGBytes + tid * 16);
@@ -589,17 +649,25 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
             [&]() { conv_main(j + 1); }, keep_gx, [&](int k) { issue(j, k); });
     };
 
-    if (nsteps > 0) {  // workgroup-uniform; the pipeline of rnnt_fused_bwd_dh
-        for (int j = -4; j < 0; ++j)
+    if (nsteps > 0) {  // workgroup-uniform; the pipeline of rnnt_fused_bwd_dh, with the records two steps further ahead
+        for (int j = -6; j < 0; ++j) issue(j, kDmaPerStep + 1);
+        for (int j = -4; j < 0; ++j) issue(j, kDmaPerStep);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int j = -2; j < 0; ++j) {  // Q tiles 0 and 1, their rows from the records that have just landed
+            take_rows(read_rows(j + 2));
 #pragma unroll
-            for (int k = 0; k <= kDmaPerStep + 1; ++k) issue(j, k);
+            for (int k = 0; k < kDmaPerStep; ++k) issue(j, k);
+        }
+        take_rows(read_rows(2));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         conv_main(0);
         conv_finish(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int j = 0; j < nsteps; ++j) {
+            const int next_rows = read_rows(j + 3);  // (records of tile j + 3: landed since the end of step j - 1)
             mma(j);  // (and the DMAs of step j)
             if (j + 1 < nsteps) conv_finish(j + 1);
+            take_rows(next_rows);
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W::kStep) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -730,30 +798,36 @@ template <typename DT>
 rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logits, const int *labels,
                         const int *act_lens, const int *label_lens, int V, int ldv, int B, const float *grad_out,
                         int grad_out_stride, float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
-                        const Lattice &L, void *bwd_ws, const rnntOptions &o) {
+                        const Lattice &L, void *bwd_ws, const rnntOptions &o, long long row_cap, const int *rowmap) {
     typedef typename DT::elem E;
     const int padded = ldv >= (V + kBM - 1) / kBM * kBM;  // every tile of every row may be read in full
-    const long long rows = (long long)B * o.maxT * o.maxU;
+    // rows the grids are cut for: every row of the tensor, or (compacted order) what the logits buffer holds
+    const long long tensor_rows = (long long)B * o.maxT * o.maxU;
+    const long long rows = rowmap && row_cap < tensor_rows ? row_cap : tensor_rows;
+    const Compact cmap = {rowmap, L.spans, B};
     const DwPlan p = dw_plan(rows, V);
     const BwdWorkspace w = carve_bwd(bwd_ws, p);
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const long long row_tiles = (rows + kBM - 1) / kBM;
     if (row_tiles > 0x7fffffffLL || (p.coef_rows + 255) / 256 > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     hipLaunchKernelGGL(rnnt_bwd_node_coefs, dim3((unsigned)((p.coef_rows + 255) / 256)), dim3(256), 0, st, w.coefs, labels,
-                       act_lens, label_lens, L, grad_out, grad_out_stride, grad_scale, o.maxT, o.maxU, rows, p.coef_rows);
+                       act_lens, label_lens, L, grad_out, grad_out_stride, grad_scale, o.maxT, o.maxU, rows, p.coef_rows, cmap);
     if (o.stage_events && o.stage_events[1]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[1]), st);
     if (grad_hidden) {
+        if (rowmap)
+            hipLaunchKernelGGL((rnnt_fused_bwd_zero_padding<DT>), dim3((unsigned)((tensor_rows + 255) / 256)), dim3(256), 0, st,
+                               static_cast<E *>(grad_hidden), L.spans, o.maxT, o.maxU, tensor_rows, rows);
 #define DH_LAUNCH(NWG, TILE0, SPLIT)                                                                              \
     hipLaunchKernelGGL((rnnt_fused_bwd_dh<DT>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st,                      \
                        static_cast<const E *>(logits), static_cast<const E *>(weight), w.coefs,                   \
                        static_cast<E *>(grad_hidden), V, ldv, padded, o.blank_label, rows, (long long)(TILE0),    \
-                       (int)(SPLIT), w.dh_partial)
+                       (int)(SPLIT), w.dh_partial, cmap)
         if (p.dh_full > 0) DH_LAUNCH(p.dh_full, 0, 1);
         if (p.dh_surplus > 0) {
             DH_LAUNCH((long long)p.dh_surplus * p.dh_vsplit, p.dh_full, p.dh_vsplit);
             const long long row0 = p.dh_full * kBM, n = rows - row0;
             hipLaunchKernelGGL((rnnt_fused_bwd_dh_merge<DT>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, w.dh_partial,
-                               p.dh_vsplit, row0, rows, static_cast<E *>(grad_hidden));
+                               p.dh_vsplit, row0, rows, static_cast<E *>(grad_hidden), cmap);
         }
 #undef DH_LAUNCH
     }
@@ -761,7 +835,7 @@ rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logi
     if (grad_weight || grad_bias) {
         hipLaunchKernelGGL((rnnt_fused_bwd_dw<DT>), dim3((unsigned)(p.nchunks * p.nvb)), dim3(kThreads), 0, st,
                            static_cast<const E *>(logits), static_cast<const E *>(hidden), w.coefs, w.partial, w.pbias, V,
-                           ldv, padded, o.blank_label, rows, p.coef_rows, p.nvb, p.steps_per_chunk);
+                           ldv, padded, o.blank_label, rows, p.coef_rows, p.nvb, p.steps_per_chunk, cmap);
         hipLaunchKernelGGL((rnnt_fused_bwd_reduce<DT>), dim3((unsigned)((V + 1) / 2)), dim3(256), 0, st, w.partial,
                            w.pbias, static_cast<E *>(grad_weight), grad_bias, V, padded, p.nvb, p.nchunks);
     }
@@ -782,12 +856,19 @@ rnntStatus_t rnnt_joint_loss_backward_workspace_size(int hidden_size, int alphab
     return RNNT_STATUS_SUCCESS;
 }
 
-rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *weight, const void *logits,
-                                              int logits_row_stride, const int *labels, const int *act_lens,
-                                              const int *label_lens, int hidden_size, int alphabet_size, int minibatch,
-                                              const float *grad_out, int grad_out_stride, float grad_scale,
-                                              void *grad_hidden, void *grad_weight, float *grad_bias,
-                                              const void *workspace, void *backward_workspace, rnntOptions options) {
+rnntStatus_t rnnt_joint_loss_backward_compact_workspace_size(int hidden_size, int alphabet_size, long long logits_rows,
+                                                             size_t *size_bytes) {
+    if (!size_bytes || hidden_size != kH || alphabet_size < kBM || logits_rows <= 0) return RNNT_STATUS_INVALID_VALUE;
+    *size_bytes = carve_bwd(nullptr, dw_plan(logits_rows, alphabet_size)).bytes;
+    return RNNT_STATUS_SUCCESS;
+}
+
+static rnntStatus_t joint_loss_backward(const void *hidden, const void *weight, const void *logits,
+                                        int logits_row_stride, long long logits_rows, const void *compact_workspace,
+                                        const int *labels, const int *act_lens, const int *label_lens, int hidden_size,
+                                        int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
+                                        float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
+                                        const void *workspace, void *backward_workspace, rnntOptions options) {
     if (!hidden || !weight || !logits || !act_lens || !label_lens || !workspace || !backward_workspace)
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
@@ -812,10 +893,36 @@ rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *we
     return options.dtype == RNNT_DTYPE_BF16
                ? launch_bwd<BF16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                   grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
-                                  options)
+                                  options, logits_rows, static_cast<const int *>(compact_workspace))
                : launch_bwd<F16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                  grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
-                                 options);
+                                 options, logits_rows, static_cast<const int *>(compact_workspace));
+}
+
+rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *weight, const void *logits,
+                                              int logits_row_stride, const int *labels, const int *act_lens,
+                                              const int *label_lens, int hidden_size, int alphabet_size, int minibatch,
+                                              const float *grad_out, int grad_out_stride, float grad_scale,
+                                              void *grad_hidden, void *grad_weight, float *grad_bias,
+                                              const void *workspace, void *backward_workspace, rnntOptions options) {
+    return joint_loss_backward(hidden, weight, logits, logits_row_stride, 0, nullptr, labels, act_lens, label_lens,
+                               hidden_size, alphabet_size, minibatch, grad_out, grad_out_stride, grad_scale, grad_hidden,
+                               grad_weight, grad_bias, workspace, backward_workspace, options);
+}
+
+rnntStatus_t rnnt_joint_loss_backward_compact(const void *hidden, const void *weight, const void *logits,
+                                              int logits_row_stride, long long logits_rows, const int *labels,
+                                              const int *act_lens, const int *label_lens, int hidden_size,
+                                              int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
+                                              float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
+                                              const void *workspace, const void *compact_workspace,
+                                              void *backward_workspace, rnntOptions options) {
+    if (!compact_workspace || reinterpret_cast<uintptr_t>(compact_workspace) % 256 != 0 || logits_rows <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    if ((long long)minibatch * options.maxT * options.maxU > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
+    return joint_loss_backward(hidden, weight, logits, logits_row_stride, logits_rows, compact_workspace, labels, act_lens,
+                               label_lens, hidden_size, alphabet_size, minibatch, grad_out, grad_out_stride, grad_scale,
+                               grad_hidden, grad_weight, grad_bias, workspace, backward_workspace, options);
 }
 
 

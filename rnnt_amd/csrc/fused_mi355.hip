@@ -353,7 +353,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
                         const float *__restrict__ bias, typename DT::elem *__restrict__ logits,
                         const int *__restrict__ labels, const int *__restrict__ act_lens,
                         const int *__restrict__ label_lens, Lattice L, int maxT, int U1, int V, int ldv, int blank,
-                        long long total_rows, long long row_tile0, int vsplit, float2 *__restrict__ partial) {
+                        long long row_cap, long long row_tile0, int vsplit, float2 *__restrict__ partial, Compact cm) {
     typedef TileBuf<H> TB;
     typedef typename Mma<DT>::frag frag;
     typedef typename DT::elem E;
@@ -370,6 +370,10 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     // walks 1/S of the vocabulary tiles and leaves its {max, sum} per node in `partial` for rnnt_fused_merge.
     const long long row_tile = row_tile0 + blockIdx.x / vsplit;
     const int split = blockIdx.x % vsplit;
+    // Rows are lattice nodes: every row of the [B, maxT, U1] tensor, or (compacted order, lattice.h) the nodes inside
+    // the lattices only; the grid is cut for `row_cap` rows and the workgroups past the last node leave at once.
+    const long long total_rows = compact_total(cm, row_cap);
+    if (row_tile * kBM >= total_rows) return;  // workgroup-uniform, before the first barrier
     const long long my_row = row_tile * kBM + wave * kRowsPerWave + r;
     const long long ld_row = my_row < total_rows ? my_row : total_rows - 1;
     const int ntiles_all = (V + kBN - 1) / kBN;
@@ -379,7 +383,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
     // this wave's 32 hidden vectors: B operand, k-step s = elements [16 s + 8 h, +8) of row l & 31
     frag hid[KS];
     {
-        const E *hp = hidden + (size_t)ld_row * H + 8 * h;
+        const E *hp = hidden + (size_t)compact_row(cm, ld_row) * H + 8 * h;  // (hidden stays [B, maxT, U1, H])
 #pragma unroll
         for (int s = 0; s < KS; ++s) hid[s] = *reinterpret_cast<const frag *>(hp + 16 * s);
     }
@@ -477,7 +481,7 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
         return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores of its 32 rows are complete
-    const RowCoord c = decode_row(ld_row, maxT, U1);
+    const RowCoord c = decode_row(compact_row(cm, ld_row), maxT, U1);  // (looked up again: not kept across the walk)
     const int Tb = act_lens[c.b];
     const int Ub = label_lens[c.b];
     const bool valid = row_ok && lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub;
@@ -511,17 +515,17 @@ void rnnt_fused_proj_k1(const typename DT::elem *__restrict__ hidden, const type
 // the lattice planes, as the tail of rnnt_fused_proj_k1 does for a node one workgroup walked alone.  One wave per node.
 template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict__ partial, int vsplit, long long row0,
-                                                        long long total_rows,
+                                                        long long row_cap,
                                                         const typename DT::elem *__restrict__ logits,
                                                         const int *__restrict__ labels,
                                                         const int *__restrict__ act_lens,
                                                         const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-                                                        int V, int ldv, int blank) {
+                                                        int V, int ldv, int blank, Compact cm) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long row = row0 + (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    if (row >= total_rows) return;  // wave-uniform
+    if (row >= compact_total(cm, row_cap)) return;  // wave-uniform
     const float2 *p = partial + (size_t)(row - row0) * vsplit;
-    const RowCoord c = decode_row(row, maxT, U1);
+    const RowCoord c = decode_row(compact_row(cm, row), maxT, U1);
     const int Tb = act_lens[c.b];
     const int Ub = label_lens[c.b];
     if (!(lens_ok(Tb, Ub, maxT, U1) && c.t < Tb && c.u <= Ub)) return;
@@ -552,6 +556,28 @@ __global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict
     }
 }
 
+// rowmap[k] = tensor row of compacted node k (lattice.h: Compact), from the spans rnnt_node_spans made of the two
+// length tensors; one thread per row of the [B, maxT, U1] tensor.  A node past `cap` (the caller's logits buffer
+// holds fewer rows than there are nodes) cannot be computed: its lattice entries are set to NaN, so that its
+// utterance's cost comes out NaN instead of being formed from whatever the workspace held.
+__global__ __launch_bounds__(256) void rnnt_compact_rows(int *__restrict__ rowmap, Lattice L, int maxT, int U1,
+                                                         long long rows, long long cap) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const RowCoord c = decode_row(r, maxT, U1);
+    const NodeSpan s = L.spans[c.b];
+    if (c.t >= s.Tb || c.u >= s.Ub1) return;  // padding (an utterance whose lengths do not fit has Tb = 0)
+    const long long k = s.first + (long long)c.t * s.Ub1 + c.u;
+    if (k < cap) {
+        rowmap[k] = (int)r;
+        return;
+    }
+    const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
+    const float nan = __builtin_nanf("");
+    L.ml[o] = make_float2(nan, nan);
+    L.lp[o] = make_float2(nan, nan);
+}
+
 // Compute units of the current device (the size of one round of workgroups: the kernel runs one per CU).
 int compute_units() {
     static std::atomic<int> cached[64];
@@ -568,12 +594,22 @@ int compute_units() {
 template <typename DT, int H>
 rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *bias, void *logits,
                           const int *labels, const int *act_lens, const int *label_lens, int V, int ldv, int B,
-                          const Lattice &L, const rnntOptions &o) {
+                          const Lattice &L, const rnntOptions &o, long long row_cap, int *rowmap) {
     typedef typename DT::elem E;
-    const long long rows = (long long)B * o.maxT * o.maxU;
+    // rows the grid is cut for: every row of the tensor, or (compacted order) what the logits buffer holds
+    const long long tensor_rows = (long long)B * o.maxT * o.maxU;
+    const long long rows = rowmap && row_cap < tensor_rows ? row_cap : tensor_rows;
     const long long grid = (rows + kBM - 1) / kBM;
     if (grid > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
+    const Compact cm = {rowmap, L.spans, B};
+    if (rowmap) {
+        if (tensor_rows > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;  // rows are numbered with 32 bits
+        const rnntStatus_t s = launch_node_spans(act_lens, label_lens, B, L, o);
+        if (s != RNNT_STATUS_SUCCESS) return s;
+        hipLaunchKernelGGL(rnnt_compact_rows, dim3((unsigned)((tensor_rows + 255) / 256)), dim3(256), 0, st, rowmap, L,
+                           o.maxT, o.maxU, tensor_rows, rows);
+    }
     // One workgroup per CU at a time: `grid` row tiles take ceil(grid / CUs) rounds, and a last round with few
     // tiles costs as much as a full one (config 2: 2050 tiles on 256 CUs = 8 rounds + 2 tiles, +11 %).  The
     // surplus tiles (up to half a round) are therefore launched apart, their vocabulary shared by as many
@@ -602,14 +638,14 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
         act_lens, label_lens, L, o.maxT, o.maxU, V, ldv, o.blank_label, rows
 #define FUSED_LAUNCH(NWG, TILE0, SPLIT)                                                                      \
     hipLaunchKernelGGL((rnnt_fused_proj_k1<DT, H>), dim3((unsigned)(NWG)), dim3(kThreads), 0, st, FUSED_ARGS, \
-                       (long long)(TILE0), (int)(SPLIT), partial)
+                       (long long)(TILE0), (int)(SPLIT), partial, cm)
     if (full > 0) FUSED_LAUNCH(full, 0, 1);
     if (surplus > 0) {
         FUSED_LAUNCH(surplus * vsplit, full, vsplit);
         const long long row0 = full * kBM, n = rows - row0;
         hipLaunchKernelGGL((rnnt_fused_merge<DT>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, vsplit,
                            row0, rows, static_cast<const E *>(logits), labels, act_lens, label_lens, L, o.maxT, o.maxU, V,
-                           ldv, o.blank_label);
+                           ldv, o.blank_label, cm);
     }
 #undef FUSED_LAUNCH
 #undef FUSED_ARGS
@@ -619,11 +655,11 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
 template <typename DT>
 rnntStatus_t launch_fused_h(int H, const void *hidden, const void *weight, const float *bias, void *logits,
                             const int *labels, const int *act_lens, const int *label_lens, int V, int ldv, int B,
-                            const Lattice &L, const rnntOptions &o) {
+                            const Lattice &L, const rnntOptions &o, long long row_cap, int *rowmap) {
     switch (H) {
-        case 512: return launch_fused<DT, 512>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
-        case 256: return launch_fused<DT, 256>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
-        case 128: return launch_fused<DT, 128>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o);
+        case 512: return launch_fused<DT, 512>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o, row_cap, rowmap);
+        case 256: return launch_fused<DT, 256>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o, row_cap, rowmap);
+        case 128: return launch_fused<DT, 128>(hidden, weight, bias, logits, labels, act_lens, label_lens, V, ldv, B, L, o, row_cap, rowmap);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }
@@ -638,11 +674,19 @@ int rnnt_fused_debug_set_stamp_buffer(void *p) {
 }
 #endif
 
-rnntStatus_t rnnt_joint_loss_forward_strided(const void *hidden, const void *weight, const float *bias,
-                                             void *logits_out, int logits_row_stride, const int *labels,
-                                             const int *act_lens, const int *label_lens, int hidden_size,
-                                             int alphabet_size, int minibatch, float *costs, float *loss_out,
-                                             int reduction, void *workspace, rnntOptions options) {
+rnntStatus_t rnnt_joint_loss_compact_workspace_size(int minibatch, int maxT, int maxU, size_t *size_bytes) {
+    if (!size_bytes || minibatch <= 0 || maxT <= 0 || maxU <= 0) return RNNT_STATUS_INVALID_VALUE;
+    const long long rows = (long long)minibatch * maxT * maxU;
+    if (rows > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
+    *size_bytes = ((size_t)rows * sizeof(int) + 255) / 256 * 256;
+    return RNNT_STATUS_SUCCESS;
+}
+
+static rnntStatus_t joint_loss_forward(const void *hidden, const void *weight, const float *bias, void *logits_out,
+                                       int logits_row_stride, long long logits_rows, void *compact_workspace,
+                                       const int *labels, const int *act_lens, const int *label_lens, int hidden_size,
+                                       int alphabet_size, int minibatch, float *costs, float *loss_out, int reduction,
+                                       void *workspace, rnntOptions options) {
     if (logits_row_stride < alphabet_size) return RNNT_STATUS_INVALID_VALUE;
     // (a workgroup's 256 rows are addressed with 32-bit byte offsets)
     if ((long long)logits_row_stride * 2 * kBM > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
@@ -665,11 +709,36 @@ rnntStatus_t rnnt_joint_loss_forward_strided(const void *hidden, const void *wei
     const rnntStatus_t s =
         options.dtype == RNNT_DTYPE_BF16
             ? launch_fused_h<BF16>(hidden_size, hidden, weight, bias, logits_out, labels, act_lens, label_lens,
-                                   alphabet_size, logits_row_stride, minibatch, w, options)
+                                   alphabet_size, logits_row_stride, minibatch, w, options, logits_rows,
+                                   static_cast<int *>(compact_workspace))
             : launch_fused_h<F16>(hidden_size, hidden, weight, bias, logits_out, labels, act_lens, label_lens,
-                                  alphabet_size, logits_row_stride, minibatch, w, options);
+                                  alphabet_size, logits_row_stride, minibatch, w, options, logits_rows,
+                                  static_cast<int *>(compact_workspace));
     if (s != RNNT_STATUS_SUCCESS) return s;
     return launch_lattice_and_costs(act_lens, label_lens, minibatch, costs, loss_out, reduction, w, options);
+}
+
+rnntStatus_t rnnt_joint_loss_forward_strided(const void *hidden, const void *weight, const float *bias,
+                                             void *logits_out, int logits_row_stride, const int *labels,
+                                             const int *act_lens, const int *label_lens, int hidden_size,
+                                             int alphabet_size, int minibatch, float *costs, float *loss_out,
+                                             int reduction, void *workspace, rnntOptions options) {
+    return joint_loss_forward(hidden, weight, bias, logits_out, logits_row_stride, 0, nullptr, labels, act_lens,
+                              label_lens, hidden_size, alphabet_size, minibatch, costs, loss_out, reduction, workspace,
+                              options);
+}
+
+rnntStatus_t rnnt_joint_loss_forward_compact(const void *hidden, const void *weight, const float *bias,
+                                             void *logits_out, int logits_row_stride, long long logits_rows,
+                                             const int *labels, const int *act_lens, const int *label_lens,
+                                             int hidden_size, int alphabet_size, int minibatch, float *costs,
+                                             float *loss_out, int reduction, void *workspace, void *compact_workspace,
+                                             rnntOptions options) {
+    if (!compact_workspace || reinterpret_cast<uintptr_t>(compact_workspace) % 256 != 0 || logits_rows <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    return joint_loss_forward(hidden, weight, bias, logits_out, logits_row_stride, logits_rows, compact_workspace, labels,
+                              act_lens, label_lens, hidden_size, alphabet_size, minibatch, costs, loss_out, reduction,
+                              workspace, options);
 }
 
 

@@ -48,6 +48,23 @@ struct NodeSpan {
     int Ub1;          // label positions per frame, U_b + 1 (1 where Tb = 0, so that it can divide)
 };
 
+// The COMPACTED node order of the fused projection + loss kernels (rnnt_joint_loss_*_compact): the MFMA kernels
+// walk the nodes inside the lattices only and keep their logits in that order, so a ragged batch costs matrix work
+// and memory for its own nodes, not for the padding of the [B, maxT, U1] tensor.  rowmap[k] = row of that tensor
+// (b * maxT + t) * U1 + u of compacted node k, written by rnnt_compact_rows on the device; the number of nodes is
+// spans[B].first.  rowmap = nullptr: every row of the tensor is a node (the dense entry points).
+struct Compact {
+    const int *rowmap;
+    const NodeSpan *spans;
+    int B;
+};
+__device__ __forceinline__ long long compact_total(const Compact &c, long long cap) {
+    if (!c.rowmap) return cap;
+    const long long n = c.spans[c.B].first;  // (a scalar load)
+    return n < cap ? n : cap;
+}
+__device__ __forceinline__ long long compact_row(const Compact &c, long long k) { return c.rowmap ? c.rowmap[k] : k; }
+
 struct Lattice {      // device pointers into the workspace
     float2 *ml;       // {max_v x_v, log sum_v exp(x_v - max)} per node, kept apart: lse = m + l would
                       // round to ulp(|m|) and cost K3 that much relative accuracy on offset logits
@@ -116,5 +133,7 @@ __device__ __forceinline__ NodeCoef node_coef_from(const NodeIn &in, int t, int 
 rnntStatus_t launch_lattice_and_costs(const int *act_lens, const int *label_lens, int B, float *costs,
                                       float *loss_out, int reduction, const Lattice &L, const rnntOptions &o);
 Lattice carve_workspace(void *ws, int maxT, int maxU, int B);
+// spans[b] = {first compacted node, T_b, U_b + 1}, spans[B].first = the number of nodes (rnnt_node_spans)
+rnntStatus_t launch_node_spans(const int *act_lens, const int *label_lens, int B, const Lattice &L, const rnntOptions &o);
 
 }  // namespace rnnt_mi355_detail

@@ -1493,6 +1493,11 @@ rnntStatus_t launch_lattice_and_costs(const int *act_lens, const int *label_lens
     return RNNT_STATUS_SUCCESS;
 }
 Lattice carve_workspace(void *ws, int maxT, int maxU, int B) { return carve(ws, maxT, maxU, B); }
+rnntStatus_t launch_node_spans(const int *act_lens, const int *label_lens, int B, const Lattice &L, const rnntOptions &o) {
+    hipLaunchKernelGGL(rnnt_node_spans, dim3(1), dim3(kWave), 0, static_cast<hipStream_t>(o.stream), act_lens, label_lens,
+                       B, o.maxT, o.maxU, L.spans);
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
 }  // namespace rnnt_mi355_detail
 
 // =============================================================================================

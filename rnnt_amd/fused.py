@@ -12,6 +12,9 @@ in its epilogue, so the loss's first pass over the logits (K1) does not exist.  
 backward).  On the fused-backward path the logits are kept with their rows padded to a multiple of 128 entries:
 every row then starts on a 256-byte boundary, which the forward kernel's stores and the backward kernels' LDS-DMA
 reads want (13 % of the forward at V = 4232, profiles/r03_tuning.md), and any vocabulary size is taken.
+On that path the kernels also walk the COMPACTED node order (``rnnt_joint_loss_forward_compact``): only the lattice
+nodes inside the utterances (t < act_lens[b], u <= label_lens[b]) are multiplied, stored and read back, numbered on the
+device from the two length tensors; a ragged batch costs what its own nodes cost, not what the padded tensor would.
 
 This is an EXTENSION next to the drop-in, not part of it: its inputs are the hidden activations and the
 projection's parameters, not logits.  No CPU path, no fallback.
@@ -47,40 +50,59 @@ def _row_stride(H: int, V: int, fused_backward: bool) -> int:
 
 class _FusedJointLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction, fused_backward):
+    def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction, fused_backward, valid_nodes,
+                compact_order=True):
         lib = _lib.load()
         B, T, U1, H = hidden.shape
         V = weight.shape[0]
         dev = hidden.device
         red = _REDUCTIONS[reduction]
+        rows = B * T * U1
+        # the compacted node order goes with the fused backward (K3 wants the logits of every row of the tensor)
+        compact = bool(compact_order) and bool(fused_backward) and fused_backward_supported(H, V) and rows < 2 ** 31
+        cap = rows if (valid_nodes is None or not compact) else max(1, min(int(valid_nodes), rows))
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             bias32 = bias.detach().to(torch.float32).contiguous()
             ld = _row_stride(H, V, fused_backward)
-            logits = torch.empty((B * T * U1, ld), dtype=hidden.dtype, device=dev)  # (columns V .. ld-1: never touched)
+            logits = torch.empty((cap, ld), dtype=hidden.dtype, device=dev)  # (columns V .. ld-1: never touched)
             ws = torch.empty(_lib.workspace_bytes(T, U1, B), dtype=torch.uint8, device=dev)
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             loss = torch.empty(B if red == _lib.REDUCTION_NONE else 1, dtype=torch.float32, device=dev)
             opts = _lib.RnntOptions(stream, int(blank), T, U1, _DTYPES[hidden.dtype], None)
-            _lib.check(lib.rnnt_joint_loss_forward_strided(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
-                                                           logits.data_ptr(), ld, labels.data_ptr(),
-                                                           act_lens.data_ptr(), label_lens.data_ptr(), H, V, B,
-                                                           costs.data_ptr(), loss.data_ptr(), red, ws.data_ptr(), opts),
-                       "rnnt_joint_loss_forward_strided")
-        ctx.save_for_backward(hidden, weight, logits, labels, act_lens, label_lens, ws)
+            if compact:
+                n = ctypes.c_size_t(0)
+                _lib.check(lib.rnnt_joint_loss_compact_workspace_size(B, T, U1, ctypes.byref(n)),
+                           "rnnt_joint_loss_compact_workspace_size")
+                cws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
+                _lib.check(lib.rnnt_joint_loss_forward_compact(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
+                                                               logits.data_ptr(), ld, cap, labels.data_ptr(),
+                                                               act_lens.data_ptr(), label_lens.data_ptr(), H, V, B,
+                                                               costs.data_ptr(), loss.data_ptr(), red, ws.data_ptr(),
+                                                               cws.data_ptr(), opts),
+                           "rnnt_joint_loss_forward_compact")
+            else:
+                cws = torch.empty(0, dtype=torch.uint8, device=dev)
+                _lib.check(lib.rnnt_joint_loss_forward_strided(hidden.data_ptr(), weight.data_ptr(), bias32.data_ptr(),
+                                                               logits.data_ptr(), ld, labels.data_ptr(),
+                                                               act_lens.data_ptr(), label_lens.data_ptr(), H, V, B,
+                                                               costs.data_ptr(), loss.data_ptr(), red, ws.data_ptr(), opts),
+                           "rnnt_joint_loss_forward_strided")
+        ctx.save_for_backward(hidden, weight, logits, labels, act_lens, label_lens, ws, cws)
         ctx.blank = int(blank)
         ctx.reduction = red
         ctx.bias_dtype = bias.dtype
         ctx.fused_backward = bool(fused_backward)
-        ctx.dims = (B, T, U1, V, ld)
+        ctx.compact = compact
+        ctx.dims = (B, T, U1, V, ld, cap)
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
-        hidden, weight, logits, labels, act_lens, label_lens, ws = ctx.saved_tensors
+        hidden, weight, logits, labels, act_lens, label_lens, ws, cws = ctx.saved_tensors
         lib = _lib.load()
-        B, T, U1, V, ld = ctx.dims
+        B, T, U1, V, ld, cap = ctx.dims
         H = hidden.shape[-1]
         dev = logits.device
         with torch.cuda.device(dev):
@@ -96,20 +118,32 @@ class _FusedJointLossFunction(torch.autograd.Function):
             if ctx.fused_backward and fused_backward_supported(H, V):
                 # K3 as the prologue of the two products: the gradient w.r.t. the logits is never written
                 n = ctypes.c_size_t(0)
-                _lib.check(lib.rnnt_joint_loss_backward_workspace_size(H, V, B, T, U1, ctypes.byref(n)),
-                           "rnnt_joint_loss_backward_workspace_size")
+                if ctx.compact:
+                    _lib.check(lib.rnnt_joint_loss_backward_compact_workspace_size(H, V, cap, ctypes.byref(n)),
+                               "rnnt_joint_loss_backward_compact_workspace_size")
+                else:
+                    _lib.check(lib.rnnt_joint_loss_backward_workspace_size(H, V, B, T, U1, ctypes.byref(n)),
+                               "rnnt_joint_loss_backward_workspace_size")
                 bws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
                 if need_h:
                     g_hidden = torch.empty_like(hidden)
                 if need_w:
                     g_weight = torch.empty_like(weight)
                 gb32 = torch.empty(V, dtype=torch.float32, device=dev) if need_b else None
-                _lib.check(lib.rnnt_joint_loss_backward_strided(
-                    hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), ld, labels.data_ptr(),
-                    act_lens.data_ptr(), label_lens.data_ptr(), H, V, B, go.data_ptr(), stride, ctypes.c_float(scale),
-                    g_hidden.data_ptr() if need_h else None, g_weight.data_ptr() if need_w else None,
-                    gb32.data_ptr() if need_b else None, ws.data_ptr(), bws.data_ptr(), opts),
-                    "rnnt_joint_loss_backward_strided")
+                outs = (g_hidden.data_ptr() if need_h else None, g_weight.data_ptr() if need_w else None,
+                        gb32.data_ptr() if need_b else None)
+                if ctx.compact:
+                    _lib.check(lib.rnnt_joint_loss_backward_compact(
+                        hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), ld, cap, labels.data_ptr(),
+                        act_lens.data_ptr(), label_lens.data_ptr(), H, V, B, go.data_ptr(), stride,
+                        ctypes.c_float(scale), *outs, ws.data_ptr(), cws.data_ptr(), bws.data_ptr(), opts),
+                        "rnnt_joint_loss_backward_compact")
+                else:
+                    _lib.check(lib.rnnt_joint_loss_backward_strided(
+                        hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), ld, labels.data_ptr(),
+                        act_lens.data_ptr(), label_lens.data_ptr(), H, V, B, go.data_ptr(), stride,
+                        ctypes.c_float(scale), *outs, ws.data_ptr(), bws.data_ptr(), opts),
+                        "rnnt_joint_loss_backward_strided")
                 if need_b:
                     g_bias = gb32.to(ctx.bias_dtype)
             else:
@@ -126,11 +160,21 @@ class _FusedJointLossFunction(torch.autograd.Function):
                     g_weight = torch.mm(g2.t(), h2)
                 if need_b:
                     g_bias = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
-        return g_hidden, g_weight, g_bias, None, None, None, None, None, None
+        return g_hidden, g_weight, g_bias, None, None, None, None, None, None, None, None
+
+
+def count_lattice_nodes(act_lens, label_lens) -> int:
+    """Sum of ``T_b * (U_b + 1)`` over the batch from HOST copies of the two length tensors (any integer sequences or
+    CPU tensors): the ``valid_nodes`` argument of :func:`fused_joint_loss`.  The reference has both on the host when
+    it calls the loss (``enc_output_lengths`` comes out of ``pad_packed_sequence``, ``tokens_length`` out of the data
+    loader: /root/reference/src/rnnt/model.py:104-116), so the count costs no device round trip there."""
+    t = torch.as_tensor(act_lens, device="cpu").to(torch.int64).clamp_min(0)
+    u = torch.as_tensor(label_lens, device="cpu").to(torch.int64).clamp_min(0)
+    return int((t * (u + 1)).sum())
 
 
 def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean",
-                     min_nodes=DEFAULT_MIN_NODES, fused_backward=True):
+                     min_nodes=DEFAULT_MIN_NODES, fused_backward=True, valid_nodes=None, compact_order=True):
     """``RNNTLoss(blank, reduction)(hidden @ weight.T + bias, labels, act_lens, label_lens)`` in one pass.
 
     Lattices of fewer than ``min_nodes`` nodes (``B*T*(U+1)``) are computed as exactly that composition instead
@@ -143,6 +187,11 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         weight, bias: the parameters of ``Linear(H -> V)`` (``mlp.2`` of the reference's ``JointNet``);
             weight in ``hidden``'s dtype, ``[V, H]`` contiguous.
         labels, act_lens, label_lens, blank, reduction: as :func:`rnnt_amd.rnnt_loss`.
+        valid_nodes: optional upper bound of the number of lattice nodes ``sum_b T_b (U_b + 1)``, known on the host
+            (:func:`count_lattice_nodes`).  The kernels skip the padding of a ragged batch either way (they number
+            the nodes on the device); with the bound the logits buffer and the launch grids are cut for the nodes
+            instead of for ``B*T*(U+1)`` rows.  A bound below the true count makes the affected costs NaN.
+        compact_order: False runs the kernels over every row of the tensor, padding included (for A/B runs).
     """
     if reduction not in _REDUCTIONS:
         raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
@@ -193,7 +242,7 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         logits = torch.nn.functional.linear(hidden.float(), weight.float(), bias.float()).to(hidden.dtype)
         return rnnt_loss(logits, labels, act_lens, label_lens, blank=blank, reduction=reduction, check_lengths=False)
     return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction,
-                                         fused_backward)
+                                         fused_backward, valid_nodes, compact_order)
 
 
 class FusedJointLoss(torch.nn.Module):
@@ -201,7 +250,7 @@ class FusedJointLoss(torch.nn.Module):
     projection (``joint.mlp[2]`` of the reference's or this package's ``JointNet``) at call time."""
 
     def __init__(self, blank: int = 0, reduction: str = "mean", min_nodes: int = DEFAULT_MIN_NODES,
-                 fused_backward: bool = True):
+                 fused_backward: bool = True, compact_order: bool = True):
         super().__init__()
         if reduction not in _REDUCTIONS:
             raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
@@ -209,7 +258,9 @@ class FusedJointLoss(torch.nn.Module):
         self.reduction = reduction
         self.min_nodes = min_nodes  # smaller lattices take the library GEMM + RNNTLoss (see fused_joint_loss)
         self.fused_backward = fused_backward  # False: K3 + two library GEMMs (the round-2 backward), for A/B runs
+        self.compact_order = compact_order    # False: every row of the tensor, padding included, for A/B runs
 
-    def forward(self, hidden, projection: torch.nn.Linear, labels, act_lens, label_lens):
+    def forward(self, hidden, projection: torch.nn.Linear, labels, act_lens, label_lens, valid_nodes=None):
         return fused_joint_loss(hidden, projection.weight, projection.bias, labels, act_lens, label_lens,
-                                self.blank, self.reduction, self.min_nodes, self.fused_backward)
+                                self.blank, self.reduction, self.min_nodes, self.fused_backward, valid_nodes,
+                                self.compact_order)

@@ -127,11 +127,22 @@ class JointNet(nn.Module):
             raise NotImplementedError
         hidden = self.hidden(enc_state, dec_state)
         out = self.mlp[2]
+        # Lengths still on the host (the reference's are: model.py:104-111 moves them to the device for the loss): the
+        # number of lattice nodes is counted there, for free, and the fused kernels are cut for the nodes of a ragged
+        # batch instead of for the padded tensor; then the lengths go to the device as the reference's do.
+        valid_nodes = None
+        if not act_lens.is_cuda and not label_lens.is_cuda:
+            from .fused import count_lattice_nodes
+
+            valid_nodes = count_lattice_nodes(act_lens, label_lens)
+        act_lens = act_lens.to(device=hidden.device, dtype=torch.int32)
+        label_lens = label_lens.to(device=hidden.device, dtype=torch.int32)
         if hidden.dtype in (torch.bfloat16, torch.float16):
             from .fused import SUPPORTED_HIDDEN, fused_joint_loss
 
             if hidden.size(-1) in SUPPORTED_HIDDEN and out.out_features >= 64 and out.bias is not None:
-                return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction)
+                return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction,
+                                        valid_nodes=valid_nodes)
         from .loss import rnnt_loss
 
         return rnnt_loss(out(hidden), labels, act_lens, label_lens, blank=blank, reduction=reduction)

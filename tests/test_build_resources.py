@@ -114,5 +114,8 @@ def test_fused_backward_counts_its_own_vector_memory_waits(tmp_path):
             elif barriers[0] < i < barriers[-2] and not in_asm:
                 region.append(t)
         foreign = [t for t in region if re.match(r"(s_waitcnt[^\n]*vmcnt|global_load|buffer_load|scratch_|flat_)", t)]
+        # (vmcnt(63) is the counter's maximum: such a wait, which hipcc puts in front of a __syncthreads() it finds
+        # nothing to wait for, waits for no vector-memory operation at all)
+        foreign = [t for t in foreign if "vmcnt(63)" not in t]
         assert not foreign, (name, foreign[:5])
         assert "global_load_lds_dwordx4" in body and "v_mfma_f32_32x32x16" in body
