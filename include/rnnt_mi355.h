@@ -178,6 +178,22 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
                                         void *workspace, void *stream);
 
 /*
+ * The pair above for a ragged batch whose consumer ignores the rows outside the utterances' lattices — the loss does
+ * (/root/reference/src/rnnt/model.py:116 on the logits of :46-59), and rnnt_joint_loss_forward_compact /
+ * _backward_compact never touch them: forward writes hidden[b,t,u,:] only for t < act_lens[b] and u <= label_lens[b]
+ * (the other rows of `hidden` keep whatever they held); backward reads hidden and grad_hidden only there and takes the
+ * gradient of every other row as zero (grad_enc_proj of frames past act_lens[b] and grad_dec_proj of positions past
+ * label_lens[b] come out as zeros).  An utterance whose lengths do not fit the tensor has no rows.  Lengths are read
+ * on the device.  Same workspace size.
+ */
+rnntStatus_t rnnt_joint_hidden_forward_ragged(const void *enc_proj, const void *dec_proj, void *hidden,
+                                              const int *act_lens, const int *label_lens, int B, int T, int U1, int H,
+                                              rnntDtype_t dtype, void *stream);
+rnntStatus_t rnnt_joint_hidden_backward_ragged(const void *hidden, const void *grad_hidden, void *grad_enc_proj,
+                                               void *grad_dec_proj, const int *act_lens, const int *label_lens, int B,
+                                               int T, int U1, int H, rnntDtype_t dtype, void *workspace, void *stream);
+
+/*
  * ---- the joint's output projection fused with the loss's first pass ----------
  *
  * Replaces the pair  logits = Linear(H -> V)(hidden)  (/root/reference/src/rnnt/model.py:17,59) and the
@@ -267,8 +283,9 @@ rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *we
  * them) — and keep the logits in that order: row k of `logits` belongs to the k-th node, not to row k of the
  * [B, maxT, U1] tensor.  Matrix work, logits memory and HBM traffic then follow the sum of T_b (U_b + 1), not
  * B maxT U1 (a batch cut like BASELINE config 3 has 35 % of its rows inside lattices).  hidden and grad_hidden stay
- * [B, maxT, U1, H]: the kernels gather the nodes' hidden vectors and scatter their gradients; the rows of grad_hidden
- * that are no node are set to zero, hidden's are never read.
+ * [B, maxT, U1, H]: the kernels gather the nodes' hidden vectors and scatter their gradients; hidden's rows that are
+ * no node are never read; grad_hidden's are set to zero (zero_padding_rows = 1) or left untouched (0: for a consumer
+ * that skips them itself, rnnt_joint_hidden_backward_ragged).
  *   logits_rows        rows the logits buffer holds (logits_rows * logits_row_stride elements): an upper bound of the
  *                      number of nodes known on the host; minibatch * maxT * maxU always suffices.  The grids are cut
  *                      for it, workgroups past the last node leave at once.  Should the lattices hold MORE nodes, the
@@ -293,8 +310,8 @@ rnntStatus_t rnnt_joint_loss_backward_compact(const void *hidden, const void *we
                                               int logits_row_stride, long long logits_rows, const int *labels,
                                               const int *act_lens, const int *label_lens, int hidden_size,
                                               int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
-                                              float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
-                                              const void *workspace, const void *compact_workspace,
+                                              float grad_scale, void *grad_hidden, int zero_padding_rows, void *grad_weight,
+                                              float *grad_bias, const void *workspace, const void *compact_workspace,
                                               void *backward_workspace, rnntOptions options);
 
 /*

@@ -49,6 +49,8 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
+    "rnnt_joint_hidden_forward_ragged",
+    "rnnt_joint_hidden_backward_ragged",
     "rnnt_row_argmax",
     "rnnt_row_max_logp",
     "rnnt_event_create",
@@ -153,7 +155,7 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_loss_backward_compact_workspace_size.restype = ctypes.c_int
         lib.rnnt_joint_loss_backward_compact.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_longlong, ip, ip, ip,
                                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int,
-                                                         ctypes.c_float, vp, vp, fp, vp, vp, vp, RnntOptions]
+                                                         ctypes.c_float, vp, ctypes.c_int, vp, fp, vp, vp, vp, RnntOptions]
         lib.rnnt_joint_loss_backward_compact.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -164,6 +166,12 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_hidden_backward.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_joint_hidden_backward.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_forward_ragged.argtypes = [vp, vp, vp, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.rnnt_joint_hidden_forward_ragged.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_backward_ragged.argtypes = [vp, vp, vp, vp, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
+        lib.rnnt_joint_hidden_backward_ragged.restype = ctypes.c_int
         lib.rnnt_row_argmax.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_row_argmax.restype = ctypes.c_int
         lib.rnnt_row_max_logp.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_void_p]

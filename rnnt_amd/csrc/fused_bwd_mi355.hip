@@ -798,7 +798,8 @@ template <typename DT>
 rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logits, const int *labels,
                         const int *act_lens, const int *label_lens, int V, int ldv, int B, const float *grad_out,
                         int grad_out_stride, float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
-                        const Lattice &L, void *bwd_ws, const rnntOptions &o, long long row_cap, const int *rowmap) {
+                        const Lattice &L, void *bwd_ws, const rnntOptions &o, long long row_cap, const int *rowmap,
+                        bool zero_padding_rows) {
     typedef typename DT::elem E;
     const int padded = ldv >= (V + kBM - 1) / kBM * kBM;  // every tile of every row may be read in full
     // rows the grids are cut for: every row of the tensor, or (compacted order) what the logits buffer holds
@@ -814,7 +815,7 @@ rnntStatus_t launch_bwd(const void *hidden, const void *weight, const void *logi
                        act_lens, label_lens, L, grad_out, grad_out_stride, grad_scale, o.maxT, o.maxU, rows, p.coef_rows, cmap);
     if (o.stage_events && o.stage_events[1]) (void)hipEventRecord(static_cast<hipEvent_t>(o.stage_events[1]), st);
     if (grad_hidden) {
-        if (rowmap)
+        if (rowmap && zero_padding_rows)
             hipLaunchKernelGGL((rnnt_fused_bwd_zero_padding<DT>), dim3((unsigned)((tensor_rows + 255) / 256)), dim3(256), 0, st,
                                static_cast<E *>(grad_hidden), L.spans, o.maxT, o.maxU, tensor_rows, rows);
 #define DH_LAUNCH(NWG, TILE0, SPLIT)                                                                              \
@@ -868,7 +869,8 @@ static rnntStatus_t joint_loss_backward(const void *hidden, const void *weight, 
                                         const int *labels, const int *act_lens, const int *label_lens, int hidden_size,
                                         int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
                                         float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
-                                        const void *workspace, void *backward_workspace, rnntOptions options) {
+                                        const void *workspace, void *backward_workspace, rnntOptions options,
+                                        bool zero_padding_rows = true) {
     if (!hidden || !weight || !logits || !act_lens || !label_lens || !workspace || !backward_workspace)
         return RNNT_STATUS_INVALID_VALUE;
     if (!labels && options.maxU > 1) return RNNT_STATUS_INVALID_VALUE;
@@ -893,10 +895,10 @@ static rnntStatus_t joint_loss_backward(const void *hidden, const void *weight, 
     return options.dtype == RNNT_DTYPE_BF16
                ? launch_bwd<BF16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                   grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
-                                  options, logits_rows, static_cast<const int *>(compact_workspace))
+                                  options, logits_rows, static_cast<const int *>(compact_workspace), zero_padding_rows)
                : launch_bwd<F16>(hidden, weight, logits, labels, act_lens, label_lens, alphabet_size, logits_row_stride, minibatch, grad_out,
                                  grad_out_stride, grad_scale, grad_hidden, grad_weight, grad_bias, w, backward_workspace,
-                                 options, logits_rows, static_cast<const int *>(compact_workspace));
+                                 options, logits_rows, static_cast<const int *>(compact_workspace), zero_padding_rows);
 }
 
 rnntStatus_t rnnt_joint_loss_backward_strided(const void *hidden, const void *weight, const void *logits,
@@ -914,15 +916,16 @@ rnntStatus_t rnnt_joint_loss_backward_compact(const void *hidden, const void *we
                                               int logits_row_stride, long long logits_rows, const int *labels,
                                               const int *act_lens, const int *label_lens, int hidden_size,
                                               int alphabet_size, int minibatch, const float *grad_out, int grad_out_stride,
-                                              float grad_scale, void *grad_hidden, void *grad_weight, float *grad_bias,
-                                              const void *workspace, const void *compact_workspace,
+                                              float grad_scale, void *grad_hidden, int zero_padding_rows, void *grad_weight,
+                                              float *grad_bias, const void *workspace, const void *compact_workspace,
                                               void *backward_workspace, rnntOptions options) {
     if (!compact_workspace || reinterpret_cast<uintptr_t>(compact_workspace) % 256 != 0 || logits_rows <= 0)
         return RNNT_STATUS_INVALID_VALUE;
     if ((long long)minibatch * options.maxT * options.maxU > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;
     return joint_loss_backward(hidden, weight, logits, logits_row_stride, logits_rows, compact_workspace, labels, act_lens,
                                label_lens, hidden_size, alphabet_size, minibatch, grad_out, grad_out_stride, grad_scale,
-                               grad_hidden, grad_weight, grad_bias, workspace, backward_workspace, options);
+                               grad_hidden, grad_weight, grad_bias, workspace, backward_workspace, options,
+                               zero_padding_rows != 0);
 }
 
 

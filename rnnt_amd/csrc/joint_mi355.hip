@@ -121,12 +121,22 @@ template <typename DT, int VEC>
 __global__ __launch_bounds__(kJW *kWave) void joint_hidden_fwd(const typename DT::elem *__restrict__ enc_proj,
                                                                 const typename DT::elem *__restrict__ dec_proj,
                                                                 typename DT::elem *__restrict__ hidden,
-                                                                long long BT, int T, int U1, int H) {
+                                                                long long BT, int T, int U1, int H,
+                                                                const int *__restrict__ act_lens,
+                                                                const int *__restrict__ label_lens) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const long long p = (long long)blockIdx.x * kJW + wave;  // = b*T + t
     if (p >= BT) return;
     const int b = (int)(p / T);
+    // ragged call: only the rows inside the utterance's lattice (t < T_b, u <= U_b) are written; an utterance whose
+    // lengths do not fit the tensor has none (as everywhere in this library)
+    int nu = U1;
+    if (act_lens) {
+        const int Tb = act_lens[b], Ub = label_lens[b];
+        if (!(Tb >= 1 && Tb <= T && Ub >= 0 && Ub < U1) || (int)(p - (long long)b * T) >= Tb) return;  // wave-uniform
+        nu = Ub + 1;
+    }
     const int col0 = blockIdx.y * (kWave * VEC * kJCH) + lane * VEC;
 
     Piece<DT, VEC> e[kJCH];
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(kJW *kWave) void joint_hidden_fwd(const typename DT
     const typename DT::elem *drow = dec_proj + (size_t)b * U1 * H;
     typename DT::elem *hrow = hidden + (size_t)p * U1 * H;
 #pragma unroll 4
-    for (int u = 0; u < U1; ++u) {
+    for (int u = 0; u < nu; ++u) {
 #pragma unroll
         for (int k = 0; k < kJCH; ++k) {
             if (!ok[k]) continue;
@@ -167,7 +177,9 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
                                                                 const typename DT::elem *__restrict__ grad_hidden,
                                                                 typename DT::elem *__restrict__ grad_enc_proj,
                                                                 float *__restrict__ partial, long long items, int T,
-                                                                int U1, int H, int nchunk, int nslice) {
+                                                                int U1, int H, int nchunk, int nslice,
+                                                                const int *__restrict__ act_lens,
+                                                                const int *__restrict__ label_lens) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long w = (long long)blockIdx.x * kBW + threadIdx.x / kWave;
     if (w >= items) return;
@@ -180,6 +192,15 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
     const int colc = ok ? col : H - VEC;  // surplus lanes read a valid piece and store nothing
     const int t0 = chunk * kTC;
     const int nt = T - t0 < kTC ? T - t0 : kTC;  // wave-uniform
+    // ragged call: rows outside the utterance's lattice are not read (whatever they hold) and count as zero gradient:
+    // ntv frames of this chunk and nu label positions lie inside
+    int ntv = nt, nu = U1;
+    if (act_lens) {
+        const int Tb = act_lens[b], Ub = label_lens[b];
+        const bool fit = Tb >= 1 && Tb <= T && Ub >= 0 && Ub < U1;
+        ntv = fit ? min(max(Tb - t0, 0), nt) : 0;
+        nu = fit && ntv > 0 ? Ub + 1 : 0;
+    }
 
     float acc_e[kTC][VEC];
 #pragma unroll
@@ -192,8 +213,8 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
     const typename DT::elem *gp = grad_hidden + ((size_t)b * T + t0) * frame_stride + colc;
     float *pp = partial + ((size_t)b * nchunk + chunk) * frame_stride + col;
 
-    if (nt == kTC) {  // every chunk but the last: unconditional loads, fully unrolled
-        for (int u = 0; u < U1; ++u) {
+    if (ntv == kTC) {  // every chunk but the last: unconditional loads, fully unrolled
+        for (int u = 0; u < nu; ++u) {
             float acc_d[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc_d[j] = 0.f;
@@ -211,31 +232,35 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
             }
             if (ok) store4<F32, VEC>(pp + (size_t)u * H, acc_d);
         }
-    } else {
-        for (int u = 0; u < U1; ++u) {
+    } else if (ntv > 0) {
+        // a chunk that ends inside (the last frames of the tensor or, ragged, of the utterance): the same unconditional,
+        // fully unrolled loads — a frame past the end reads the chunk's last valid frame again and counts as zero (a
+        // select: whatever was read is dropped).  With the loads under a per-frame condition hipcc waits for each one.
+        for (int u = 0; u < nu; ++u) {
             float acc_d[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc_d[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < kTC; ++i) {
-                if (i < nt) {
-                    float hx[VEC], gx[VEC];
-                    load4_nt<DT, VEC>(hp + i * frame_stride + (size_t)u * H, hx);
-                    load4_nt<DT, VEC>(gp + i * frame_stride + (size_t)u * H, gx);
+                const int ii = i < ntv ? i : ntv - 1;  // wave-uniform
+                float hx[VEC], gx[VEC];
+                load4_nt<DT, VEC>(hp + ii * frame_stride + (size_t)u * H, hx);
+                load4_nt<DT, VEC>(gp + ii * frame_stride + (size_t)u * H, gx);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const float v = gx[j] * (1.f - hx[j] * hx[j]);
-                        acc_d[j] += v;
-                        acc_e[i][j] += v;
-                    }
+                for (int j = 0; j < VEC; ++j) {
+                    const float v = i < ntv ? gx[j] * (1.f - hx[j] * hx[j]) : 0.f;
+                    acc_d[j] += v;
+                    acc_e[i][j] += v;
                 }
             }
             if (ok) store4<F32, VEC>(pp + (size_t)u * H, acc_d);
         }
     }
     if (ok) {
+        const float zero[VEC] = {};
+        for (int u = nu; u < U1; ++u) store4<F32, VEC>(pp + (size_t)u * H, zero);  // (ragged: positions past U_b)
 #pragma unroll
-        for (int i = 0; i < kTC; ++i)
+        for (int i = 0; i < kTC; ++i)  // (ragged: frames past T_b get their zeros)
             if (i < nt) store4<DT, VEC>(grad_enc_proj + ((size_t)b * T + t0 + i) * H + col, acc_e[i]);
     }
 }
@@ -380,7 +405,7 @@ inline bool shape_ok(int B, int T, int U1, int H) {
 
 template <typename DT>
 rnntStatus_t launch_fwd(const void *enc_proj, const void *dec_proj, void *hidden, int B, int T, int U1, int H,
-                        hipStream_t st) {
+                        hipStream_t st, const int *act_lens = nullptr, const int *label_lens = nullptr) {
     typedef typename DT::elem E;
     const bool vec = H % DT::EPC == 0 && aligned16(enc_proj) && aligned16(dec_proj) && aligned16(hidden);
     const long long BT = (long long)B * T;
@@ -390,12 +415,12 @@ rnntStatus_t launch_fwd(const void *enc_proj, const void *dec_proj, void *hidden
         const int cw = kWave * DT::EPC * kJCH;
         hipLaunchKernelGGL((joint_hidden_fwd<DT, DT::EPC>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0,
                            st, static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
-                           static_cast<E *>(hidden), BT, T, U1, H);
+                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens);
     } else {
         const int cw = kWave * kJCH;
         hipLaunchKernelGGL((joint_hidden_fwd<DT, 1>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0, st,
                            static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
-                           static_cast<E *>(hidden), BT, T, U1, H);
+                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens);
     }
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
@@ -404,7 +429,8 @@ inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintp
 
 template <typename DT>
 rnntStatus_t launch_bwd(const void *hidden, const void *grad_hidden, void *grad_enc_proj, void *grad_dec_proj,
-                        int B, int T, int U1, int H, void *workspace, hipStream_t st) {
+                        int B, int T, int U1, int H, void *workspace, hipStream_t st, const int *act_lens = nullptr,
+                        const int *label_lens = nullptr) {
     typedef typename DT::elem E;
     const size_t piece = 4 * sizeof(E);
     const bool vec = H % 4 == 0 && aligned_to(hidden, piece) && aligned_to(grad_hidden, piece) &&
@@ -419,11 +445,11 @@ rnntStatus_t launch_bwd(const void *hidden, const void *grad_hidden, void *grad_
     if (vec) {
         hipLaunchKernelGGL((joint_hidden_bwd<DT, 4>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
                            static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
-                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice);
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens);
     } else {
         hipLaunchKernelGGL((joint_hidden_bwd<DT, 1>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
                            static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
-                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice);
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens);
     }
     if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
     const size_t total = (size_t)B * U1 * H;
@@ -470,6 +496,43 @@ rnntStatus_t rnnt_joint_hidden_backward(const void *hidden, const void *grad_hid
             return launch_bwd<BF16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
         case RNNT_DTYPE_F16:
             return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t rnnt_joint_hidden_forward_ragged(const void *enc_proj, const void *dec_proj, void *hidden,
+                                              const int *act_lens, const int *label_lens, int B, int T, int U1, int H,
+                                              rnntDtype_t dtype, void *stream) {
+    if (enc_proj == nullptr || dec_proj == nullptr || hidden == nullptr || act_lens == nullptr || label_lens == nullptr ||
+        !shape_ok(B, T, U1, H))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32: return launch_fwd<F32>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens);
+        case RNNT_DTYPE_BF16: return launch_fwd<BF16>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens);
+        case RNNT_DTYPE_F16: return launch_fwd<F16>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t rnnt_joint_hidden_backward_ragged(const void *hidden, const void *grad_hidden, void *grad_enc_proj,
+                                               void *grad_dec_proj, const int *act_lens, const int *label_lens, int B,
+                                               int T, int U1, int H, rnntDtype_t dtype, void *workspace, void *stream) {
+    if (hidden == nullptr || grad_hidden == nullptr || grad_enc_proj == nullptr || grad_dec_proj == nullptr ||
+        act_lens == nullptr || label_lens == nullptr || workspace == nullptr || !shape_ok(B, T, U1, H) ||
+        !aligned16(workspace))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32:
+            return launch_bwd<F32>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                   label_lens);
+        case RNNT_DTYPE_BF16:
+            return launch_bwd<BF16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                    label_lens);
+        case RNNT_DTYPE_F16:
+            return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                   label_lens);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }

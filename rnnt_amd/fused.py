@@ -51,7 +51,7 @@ def _row_stride(H: int, V: int, fused_backward: bool) -> int:
 class _FusedJointLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hidden, weight, bias, labels, act_lens, label_lens, blank, reduction, fused_backward, valid_nodes,
-                compact_order=True):
+                compact_order=True, zero_padding_grad=True):
         lib = _lib.load()
         B, T, U1, H = hidden.shape
         V = weight.shape[0]
@@ -94,6 +94,7 @@ class _FusedJointLossFunction(torch.autograd.Function):
         ctx.bias_dtype = bias.dtype
         ctx.fused_backward = bool(fused_backward)
         ctx.compact = compact
+        ctx.zero_padding_grad = bool(zero_padding_grad)
         ctx.dims = (B, T, U1, V, ld, cap)
         return loss
 
@@ -136,7 +137,8 @@ class _FusedJointLossFunction(torch.autograd.Function):
                     _lib.check(lib.rnnt_joint_loss_backward_compact(
                         hidden.data_ptr(), weight.data_ptr(), logits.data_ptr(), ld, cap, labels.data_ptr(),
                         act_lens.data_ptr(), label_lens.data_ptr(), H, V, B, go.data_ptr(), stride,
-                        ctypes.c_float(scale), *outs, ws.data_ptr(), cws.data_ptr(), bws.data_ptr(), opts),
+                        ctypes.c_float(scale), outs[0], 1 if ctx.zero_padding_grad else 0, outs[1], outs[2],
+                        ws.data_ptr(), cws.data_ptr(), bws.data_ptr(), opts),
                         "rnnt_joint_loss_backward_compact")
                 else:
                     _lib.check(lib.rnnt_joint_loss_backward_strided(
@@ -160,7 +162,16 @@ class _FusedJointLossFunction(torch.autograd.Function):
                     g_weight = torch.mm(g2.t(), h2)
                 if need_b:
                     g_bias = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
-        return g_hidden, g_weight, g_bias, None, None, None, None, None, None, None, None
+        return g_hidden, g_weight, g_bias, None, None, None, None, None, None, None, None, None
+
+
+def fused_joint_loss_skips_padding(hidden, weight, min_nodes=DEFAULT_MIN_NODES) -> bool:
+    """Whether :func:`fused_joint_loss` on these operands walks the compacted node order, i.e. never reads the rows of
+    ``hidden`` outside the lattices (and may leave their gradient unwritten, ``zero_padding_grad=False``)."""
+    B, T, U1, H = hidden.shape
+    rows = B * T * U1
+    return (hidden.dtype in (torch.bfloat16, torch.float16) and fused_backward_supported(H, weight.shape[0])
+            and min_nodes <= rows < 2 ** 31)
 
 
 def count_lattice_nodes(act_lens, label_lens) -> int:
@@ -174,7 +185,8 @@ def count_lattice_nodes(act_lens, label_lens) -> int:
 
 
 def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean",
-                     min_nodes=DEFAULT_MIN_NODES, fused_backward=True, valid_nodes=None, compact_order=True):
+                     min_nodes=DEFAULT_MIN_NODES, fused_backward=True, valid_nodes=None, compact_order=True,
+                     zero_padding_grad=True):
     """``RNNTLoss(blank, reduction)(hidden @ weight.T + bias, labels, act_lens, label_lens)`` in one pass.
 
     Lattices of fewer than ``min_nodes`` nodes (``B*T*(U+1)``) are computed as exactly that composition instead
@@ -192,6 +204,9 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
             the nodes on the device); with the bound the logits buffer and the launch grids are cut for the nodes
             instead of for ``B*T*(U+1)`` rows.  A bound below the true count makes the affected costs NaN.
         compact_order: False runs the kernels over every row of the tensor, padding included (for A/B runs).
+        zero_padding_grad: False leaves the rows of ``hidden.grad`` outside the lattices UNINITIALISED instead of
+            zero — only for a producer of ``hidden`` whose backward skips those rows (``joint_hidden`` with lengths);
+            honoured on the compacted path only (``fused_joint_loss_skips_padding``).
     """
     if reduction not in _REDUCTIONS:
         raise ValueError("reduction must be one of 'none', 'mean', 'sum'")
@@ -242,7 +257,7 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         logits = torch.nn.functional.linear(hidden.float(), weight.float(), bias.float()).to(hidden.dtype)
         return rnnt_loss(logits, labels, act_lens, label_lens, blank=blank, reduction=reduction, check_lengths=False)
     return _FusedJointLossFunction.apply(hidden, weight, bias, labels, act_lens, label_lens, blank, reduction,
-                                         fused_backward, valid_nodes, compact_order)
+                                         fused_backward, valid_nodes, compact_order, zero_padding_grad)
 
 
 class FusedJointLoss(torch.nn.Module):

@@ -36,24 +36,33 @@ def _workspace_bytes(B, T, U1, H) -> int:
 
 class _JointHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc_proj, dec_proj):
+    def forward(ctx, enc_proj, dec_proj, act_lens=None, label_lens=None):
         B, T, H = enc_proj.shape
         U1 = dec_proj.shape[1]
         dev = enc_proj.device
         enc_proj = enc_proj.contiguous()
         dec_proj = dec_proj.contiguous()
+        ctx.ragged = act_lens is not None
         with torch.cuda.device(dev):
             hidden = torch.empty((B, T, U1, H), dtype=enc_proj.dtype, device=dev)
-            _lib.check(_lib.load().rnnt_joint_hidden_forward(
-                enc_proj.data_ptr(), dec_proj.data_ptr(), hidden.data_ptr(), B, T, U1, H,
-                _DTYPES[enc_proj.dtype], torch.cuda.current_stream(dev).cuda_stream), "rnnt_joint_hidden_forward")
-        ctx.save_for_backward(hidden)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.ragged:  # rows outside the lattices are neither written here nor read in backward
+                _lib.check(_lib.load().rnnt_joint_hidden_forward_ragged(
+                    enc_proj.data_ptr(), dec_proj.data_ptr(), hidden.data_ptr(), act_lens.data_ptr(),
+                    label_lens.data_ptr(), B, T, U1, H, _DTYPES[enc_proj.dtype], stream),
+                    "rnnt_joint_hidden_forward_ragged")
+                ctx.save_for_backward(hidden, act_lens, label_lens)
+            else:
+                _lib.check(_lib.load().rnnt_joint_hidden_forward(
+                    enc_proj.data_ptr(), dec_proj.data_ptr(), hidden.data_ptr(), B, T, U1, H,
+                    _DTYPES[enc_proj.dtype], stream), "rnnt_joint_hidden_forward")
+                ctx.save_for_backward(hidden)
         return hidden
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_hidden):
-        (hidden,) = ctx.saved_tensors
+        hidden = ctx.saved_tensors[0]
         B, T, U1, H = hidden.shape
         dev = hidden.device
         grad_hidden = grad_hidden.to(hidden.dtype).contiguous()
@@ -61,17 +70,27 @@ class _JointHidden(torch.autograd.Function):
             grad_enc = torch.empty((B, T, H), dtype=hidden.dtype, device=dev)
             grad_dec = torch.empty((B, U1, H), dtype=hidden.dtype, device=dev)
             ws = torch.empty(_workspace_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
-            _lib.check(_lib.load().rnnt_joint_hidden_backward(
-                hidden.data_ptr(), grad_hidden.data_ptr(), grad_enc.data_ptr(), grad_dec.data_ptr(), B, T, U1, H,
-                _DTYPES[hidden.dtype], ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
-                "rnnt_joint_hidden_backward")
-        return grad_enc, grad_dec
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if ctx.ragged:
+                _, act_lens, label_lens = ctx.saved_tensors
+                _lib.check(_lib.load().rnnt_joint_hidden_backward_ragged(
+                    hidden.data_ptr(), grad_hidden.data_ptr(), grad_enc.data_ptr(), grad_dec.data_ptr(),
+                    act_lens.data_ptr(), label_lens.data_ptr(), B, T, U1, H, _DTYPES[hidden.dtype], ws.data_ptr(),
+                    stream), "rnnt_joint_hidden_backward_ragged")
+            else:
+                _lib.check(_lib.load().rnnt_joint_hidden_backward(
+                    hidden.data_ptr(), grad_hidden.data_ptr(), grad_enc.data_ptr(), grad_dec.data_ptr(), B, T, U1, H,
+                    _DTYPES[hidden.dtype], ws.data_ptr(), stream), "rnnt_joint_hidden_backward")
+        return grad_enc, grad_dec, None, None
 
 
-def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor) -> torch.Tensor:
+def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, label_lens=None) -> torch.Tensor:
     """``tanh(enc_proj[:, :, None, :] + dec_proj[:, None, :, :])`` → ``[B, T, U+1, H]`` on the MI355X.
 
     ``enc_proj`` ``[B, T, H]``, ``dec_proj`` ``[B, U+1, H]``, same dtype (fp32, bf16 or fp16) and device.
+    With ``act_lens`` / ``label_lens`` (int32 ``[B]`` on the device): the ragged form for a consumer that ignores the
+    rows outside the utterances' lattices — only rows ``t < act_lens[b]``, ``u <= label_lens[b]`` are written (the
+    others are UNINITIALISED), and backward reads ``hidden`` and its gradient only there.
     """
     if enc_proj.dim() != 3 or dec_proj.dim() != 3:
         raise ValueError("enc_proj must be [B,T,H] and dec_proj [B,U+1,H]")
@@ -84,7 +103,14 @@ def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor) -> torch.Tensor
     if not enc_proj.is_cuda or dec_proj.device != enc_proj.device:
         raise RuntimeError("rnnt_amd.joint_hidden computes on MI355X (ROCm device tensors) only; there is no CPU "
                            "path or PyTorch fallback in this package")
-    return _JointHidden.apply(enc_proj, dec_proj)
+    if (act_lens is None) != (label_lens is None):
+        raise ValueError("pass both act_lens and label_lens, or neither")
+    if act_lens is not None:
+        for name, t in (("act_lens", act_lens), ("label_lens", label_lens)):
+            if t.dtype is not torch.int32 or t.device != enc_proj.device or t.shape != (enc_proj.shape[0],) \
+                    or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous int32 [B] tensor on enc_proj's device")
+    return _JointHidden.apply(enc_proj, dec_proj, act_lens, label_lens)
 
 
 class JointNet(nn.Module):
@@ -99,10 +125,11 @@ class JointNet(nn.Module):
             nn.Linear(inner_dim, vocab_size, bias=True),
         )
 
-    def hidden(self, enc_state, dec_state):
+    def hidden(self, enc_state, dec_state, act_lens=None, label_lens=None):
         """``[B, T, U+1, inner_dim]``: what the reference's ``mlp[:2]`` (Linear + Tanh) returns on the repeated and
         concatenated (or summed) states (model.py:46-58), from ``enc_state`` ``[B, T, He]`` and ``dec_state``
-        ``[B, U+1, Hd]`` without building the ``[B, T, U+1, He+Hd]`` tensor."""
+        ``[B, U+1, Hd]`` without building the ``[B, T, U+1, He+Hd]`` tensor.  With the two length tensors: the ragged
+        form of :func:`joint_hidden` (rows outside the lattices uninitialised)."""
         first = self.mlp[0]
         if self.joint == "concat":
             he = enc_state.size(-1)
@@ -113,7 +140,7 @@ class JointNet(nn.Module):
             w_enc = w_dec = first.weight
         enc_proj = F.linear(enc_state, w_enc, first.bias)      # [B, T, H]
         dec_proj = F.linear(dec_state, w_dec)                  # [B, U+1, H]
-        return joint_hidden(enc_proj, dec_proj)
+        return joint_hidden(enc_proj, dec_proj, act_lens, label_lens)
 
     def transducer_loss(self, enc_state, dec_state, labels, act_lens, label_lens, blank=0, reduction="mean"):
         """The reference's two lines ``logits = self.joint(enc_state, dec_state)`` and
@@ -125,7 +152,6 @@ class JointNet(nn.Module):
             raise ValueError("transducer_loss takes enc_state [B, T, He] and dec_state [B, U+1, Hd]")
         if self.joint not in ("sum", "concat"):
             raise NotImplementedError
-        hidden = self.hidden(enc_state, dec_state)
         out = self.mlp[2]
         # Lengths still on the host (the reference's are: model.py:104-111 moves them to the device for the loss): the
         # number of lattice nodes is counted there, for free, and the fused kernels are cut for the nodes of a ragged
@@ -135,14 +161,21 @@ class JointNet(nn.Module):
             from .fused import count_lattice_nodes
 
             valid_nodes = count_lattice_nodes(act_lens, label_lens)
-        act_lens = act_lens.to(device=hidden.device, dtype=torch.int32)
-        label_lens = label_lens.to(device=hidden.device, dtype=torch.int32)
-        if hidden.dtype in (torch.bfloat16, torch.float16):
-            from .fused import SUPPORTED_HIDDEN, fused_joint_loss
+        act_lens = act_lens.to(device=enc_state.device, dtype=torch.int32)
+        label_lens = label_lens.to(device=enc_state.device, dtype=torch.int32)
+        if enc_state.dtype in (torch.bfloat16, torch.float16):
+            from .fused import SUPPORTED_HIDDEN, fused_joint_loss, fused_joint_loss_skips_padding
 
-            if hidden.size(-1) in SUPPORTED_HIDDEN and out.out_features >= 64 and out.bias is not None:
+            if out.in_features in SUPPORTED_HIDDEN and out.out_features >= 64 and out.bias is not None:
+                shape = torch.empty((enc_state.size(0), enc_state.size(1), dec_state.size(1), out.in_features),
+                                    dtype=enc_state.dtype, device="meta")
+                # the fused kernels walk the nodes inside the lattices only: the hidden layer then computes, and
+                # differentiates, only those rows too
+                ragged = fused_joint_loss_skips_padding(shape, out.weight)
+                hidden = self.hidden(enc_state, dec_state, *((act_lens, label_lens) if ragged else ()))
                 return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction,
-                                        valid_nodes=valid_nodes)
+                                        valid_nodes=valid_nodes, zero_padding_grad=not ragged)
+        hidden = self.hidden(enc_state, dec_state)
         from .loss import rnnt_loss
 
         return rnnt_loss(out(hidden), labels, act_lens, label_lens, blank=blank, reduction=reduction)

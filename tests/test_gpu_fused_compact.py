@@ -65,7 +65,8 @@ def forward_compact(hidden, weight, bias, labels, al, ll, ld, cap, reduction=0):
     return st, logits, costs, ws, cws
 
 
-def backward_compact(hidden, weight, logits, ld, cap, labels, al, ll, ws, cws, go, stride, scale, want=(True, True, True)):
+def backward_compact(hidden, weight, logits, ld, cap, labels, al, ll, ws, cws, go, stride, scale, want=(True, True, True),
+                     zero_padding_rows=1):
     from rnnt_amd import _lib
     from rnnt_amd.loss import _DTYPES
 
@@ -84,7 +85,7 @@ def backward_compact(hidden, weight, logits, ld, cap, labels, al, ll, ws, cws, g
     opts = _lib.RnntOptions(torch.cuda.current_stream().cuda_stream, 0, T, U1, _DTYPES[hidden.dtype], None)
     st = lib.rnnt_joint_loss_backward_compact(h.data_ptr(), w.data_ptr(), logits.data_ptr(), ld, cap, lab.data_ptr(),
                                               ald.data_ptr(), lld.data_ptr(), H, V, B, god.data_ptr(), stride,
-                                              ctypes.c_float(scale), dh.data_ptr() if want[0] else None,
+                                              ctypes.c_float(scale), dh.data_ptr() if want[0] else None, zero_padding_rows,
                                               dw.data_ptr() if want[1] else None, db.data_ptr() if want[2] else None,
                                               ws.data_ptr(), cws.data_ptr(), bws.data_ptr(), opts)
     torch.cuda.synchronize()
@@ -162,6 +163,12 @@ def test_compact_forward_and_backward(B, T, U, V, dtype, what, exact_cap):
                                        want=(False, True, True))
     assert st == 0
     check_against_k3(hidden, weight, g, None, dw2, db2)
+    # zero_padding_rows = 0: the rows outside the lattices keep what they held, the others are the same bits
+    st, dh3, _, _ = backward_compact(hidden, weight, logits, ld, cap, labels, al, ll, ws, cws, [0.5], 0, 1.0 / B,
+                                     want=(True, False, False), zero_padding_rows=0)
+    assert st == 0
+    assert torch.equal(dh3.view(-1, H)[inside], dh2.view(-1, H)[inside])
+    assert bool(torch.isnan(dh3.view(-1, H)[~inside].float()).all())
 
 
 def test_compact_on_a_batch_without_padding_equals_the_dense_calls():
@@ -305,3 +312,38 @@ def test_operator_with_and_without_the_hosts_node_count(dtype):
     on_host = joint.transducer_loss(enc, dec, lab, torch.from_numpy(al), torch.from_numpy(ll))
     on_device = joint.transducer_loss(enc, dec, lab, ald, lld)
     torch.testing.assert_close(on_host, on_device, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_ragged_hidden_layer(dtype):
+    """rnnt_joint_hidden_forward_ragged / _backward_ragged (the producer of `hidden` for the compact calls): inside the
+    lattices the same bits as the dense pair; outside, forward writes nothing and backward reads nothing."""
+    import rnnt_amd
+
+    B, T, U1, H = 5, 37, 9, 512
+    g = torch.Generator().manual_seed(11)
+    enc = torch.randn(B, T, H, generator=g).to(dtype).to(DEV)
+    dec = torch.randn(B, U1, H, generator=g).to(dtype).to(DEV)
+    al = torch.tensor([37, 5, 16, 17, 40], dtype=torch.int32)       # the last one does not fit: no rows
+    ll = torch.tensor([8, 0, 3, 8, 2], dtype=torch.int32)
+    inside = torch.zeros(B, T, U1, dtype=torch.bool)
+    for b in range(B - 1):
+        inside[b, :al[b], :ll[b] + 1] = True
+    inside = inside.to(DEV)
+    e1, d1 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    dense = rnnt_amd.joint_hidden(e1, d1)
+    e2, d2 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    ragged = rnnt_amd.joint_hidden(e2, d2, al.to(DEV), ll.to(DEV))
+    assert torch.equal(ragged[inside], dense[inside])
+    go = torch.randn(B, T, U1, H, generator=g).to(dtype).to(DEV)
+    dense.backward(torch.where(inside[..., None], go, torch.zeros_like(go)))
+    poisoned = torch.where(inside[..., None], go, torch.full_like(go, float("nan")))
+    ragged.data[~inside] = float("nan")         # (the saved tensor: backward must not read these rows either)
+    ragged.backward(poisoned)
+    assert torch.equal(e2.grad, e1.grad) and torch.equal(d2.grad, d1.grad)
+    assert float(e2.grad[1, 5:].float().abs().sum()) == 0.0 and float(d2.grad[2, 4:].float().abs().sum()) == 0.0
+    assert float(e2.grad[4].float().abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_hidden(enc, dec, al.to(DEV), None)
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_hidden(enc, dec, al.to(DEV).long(), ll.to(DEV).long())

@@ -3,7 +3,11 @@
 the reference's formulation in stock torch (repeat / cat / Linear / Tanh / Linear, model.py:46-59) + RNNTLoss, against
 rnnt_amd.JointNet + RNNTLoss (two calls) and rnnt_amd.JointNet.transducer_loss (one call).  One JSON line.
 
-    python tools/bench_joint_loss.py [--dtype bf16|f16|f32] [--shape B,T,U,V] [--reps 9] [--out file.json]
+    python tools/bench_joint_loss.py [--dtype bf16|f16|f32] [--shape B,T,U,V] [--reps 9] [--out file.json] [--ragged SEED]
+
+--ragged: utterance lengths as in BASELINE config 3 scaled to the shape (T_b uniform in [T/8, T], U_b in [U/6, U], one
+utterance at (T, U)), kept on the HOST as the reference has them when it calls the loss (model.py:104-111): the one-call
+path counts the lattice nodes there and its fused kernels walk only those (the compacted node order).
 """
 import argparse
 import json
@@ -36,6 +40,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--ragged", type=int, default=None, metavar="SEED")
+    ap.add_argument("--only-one-call", action="store_true", help="time JointNet.transducer_loss only (for profiler runs)")
     args = ap.parse_args()
     import rnnt_amd
 
@@ -49,8 +55,15 @@ def main():
     enc = torch.randn(B, T, He, device=dev, generator=g).to(dt).requires_grad_(True)
     dec = torch.randn(B, U + 1, Hd, device=dev, generator=g).to(dt).requires_grad_(True)
     labels = torch.randint(1, V, (B, U), device=dev, dtype=torch.int32, generator=g)
-    al = torch.full((B,), T, device=dev, dtype=torch.int32)
-    ll = torch.full((B,), U, device=dev, dtype=torch.int32)
+    al_host = torch.full((B,), T, dtype=torch.int32)
+    ll_host = torch.full((B,), U, dtype=torch.int32)
+    if args.ragged is not None:
+        hg = torch.Generator().manual_seed(args.ragged)
+        al_host = torch.randint(max(1, T // 8), T + 1, (B,), generator=hg, dtype=torch.int32)
+        ll_host = torch.randint(U // 6, U + 1, (B,), generator=hg, dtype=torch.int32)
+        al_host[0], ll_host[0] = T, U
+    al, ll = al_host.to(dev), ll_host.to(dev)
+    nodes = rnnt_amd.count_lattice_nodes(al_host, ll_host)
     crit = rnnt_amd.RNNTLoss(check_lengths=False)
 
     def clear():
@@ -74,11 +87,17 @@ def main():
 
     def one_call():
         clear()
-        loss = net.transducer_loss(enc, dec, labels, al, ll)
+        loss = net.transducer_loss(enc, dec, labels, al_host, ll_host)  # (lengths on the host: model.py:104-111)
         loss.backward()
         return loss
 
+    if args.only_one_call:
+        print(json.dumps({"lengths": "uniform" if args.ragged is None else f"ragged (seed {args.ragged})", "nodes": nodes,
+                          "JointNet.transducer_loss_ms": round(median_ms(one_call, args.reps), 3)}))
+        return
     res = {"shape": dict(B=B, T=T, U=U, V=V, He=He, Hd=Hd, H=H), "dtype": args.dtype,
+           "lengths": "uniform" if args.ragged is None else
+                      f"ragged (seed {args.ragged}): {nodes} of {B * T * (U + 1)} rows are lattice nodes",
            "loss": {"reference formulation": float(reference_formulation()), "JointNet + RNNTLoss": float(two_calls()),
                     "JointNet.transducer_loss": float(one_call())},
            "forward_backward_ms": {
