@@ -547,7 +547,7 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
         if (k < kDmaPerStep) {
             if (j + 2 >= 0) {
                 const int kr = wave * kDmaPerStep + k;
-#ifdef FUSED_BWD_ABLATE_LOAD  // (timing build without the records: rows by arithmetic)
+#if defined(FUSED_BWD_ABLATE_LOAD) || defined(FUSED_BWD_ARITH_ROWS)  // (timing builds: rows by arithmetic, dense order only)
                 const long long row0 = row_begin + (long long)(j + 2 < nsteps ? j + 2 : 0) * kBK;
                 hrow[k] = (int)(row0 + kr < total_rows ? row0 + kr : total_rows - 1);
 #endif
@@ -585,8 +585,10 @@ void rnnt_fused_bwd_dw(const typename DT::elem *__restrict__ logits, const typen
                                                                            wave * 256 + (lane & 3) * 32 + 24);
     };
     auto take_rows = [&](int v) {
+#ifndef FUSED_BWD_ARITH_ROWS
 #pragma unroll
         for (int k = 0; k < kDmaPerStep; ++k) hrow[k] = __builtin_amdgcn_readlane(v, k);
+#endif
     };
     float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // this thread's share of the bias gradient
     float gx[8];
