@@ -347,3 +347,72 @@ def test_ragged_hidden_layer(dtype):
         rnnt_amd.joint_hidden(enc, dec, al.to(DEV), None)
     with pytest.raises(ValueError):
         rnnt_amd.joint_hidden(enc, dec, al.to(DEV).long(), ll.to(DEV).long())
+
+
+def _random_compact_case(rng, it):
+    B = int(rng.integers(1, 9))
+    T = int(rng.integers(1, 160))
+    U = int(rng.integers(0, 24))
+    V = int(rng.choice([128, 129, 255, 520, 1027, 2048, 4234, int(rng.integers(128, 3000))]))
+    dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float16
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, 512, dtype, seed=900 + it)
+    if rng.random() < 0.3:                      # an utterance without nodes among the others
+        al = al.copy()
+        al[int(rng.integers(0, B))] = T + 1
+    rows = host_rowmap(al, ll, T, U + 1)
+    n = len(rows)
+    slack = int(rng.choice([0, 1, 37, 300]))
+    cap = max(1, min(n + slack, B * T * (U + 1)))
+    ld = (V + 127) // 128 * 128 + int(rng.choice([0, 128]))
+    return hidden, weight, bias, labels, al, ll, rows, n, cap, ld, V, dtype
+
+
+def test_compact_random_shapes():
+    """20 seeded random ragged batches (1 ... ~25 000 rows; vocabularies on both sides of the tile boundaries; logits
+    buffers with and without slack; utterances without nodes): costs against the dense call, gradients against
+    rnnt_backward + float64 products.  A one-off run of the same loop over 300 further seeds passed on this build."""
+    rng = np.random.default_rng(77)
+    for it in range(20):
+        hidden, weight, bias, labels, al, ll, rows, n, cap, ld, V, dtype = _random_compact_case(rng, it)
+        B, T, U1, H = hidden.shape
+        what = (it, B, T, U1 - 1, V, n, cap, ld)
+        st, dense, dense_costs, _ = forward_c_abi(hidden, weight, bias, labels, al, ll, ld=ld)
+        assert st == 0, what
+        st, logits, costs, ws, cws = forward_compact(poison_padding(hidden, al, ll), weight, bias, labels, al, ll, ld, cap)
+        assert st == 0, what
+        idx = torch.from_numpy(rows).to(DEV)
+        assert torch.equal(logits[:n, :V].contiguous().view(torch.int16),
+                           dense.view(-1, ld)[idx][:, :V].contiguous().view(torch.int16)), what
+        np.testing.assert_allclose(costs.cpu().numpy(), dense_costs.cpu().numpy(), rtol=2e-6, atol=0, equal_nan=True,
+                                   err_msg=str(what))
+        if n == 0:
+            continue
+        full = torch.zeros(B * T * U1, V, dtype=dtype, device=DEV)
+        full[idx] = logits[:n, :V]
+        go = rng.uniform(0.2, 1.5, B).astype(np.float32)
+        fit = (al >= 1) & (al <= T)
+        go[~fit] = 0.0                           # (a NaN cost comes with NaN gradients; the loop drops such a batch)
+        g = k3_c_abi(full.view(B, T, U1, V).contiguous(), labels, al, ll, ws, go, 1, 1.0)
+        g = torch.where(torch.from_numpy(fit).to(DEV)[:, None, None, None], g, torch.zeros_like(g))
+        st, dh, dw, db = backward_compact(poison_padding(hidden, al, ll), weight, logits, ld, cap, labels, al, ll, ws, cws,
+                                          go, 1, 1.0)
+        assert st == 0, what
+        check_against_k3(hidden, weight, g, dh, dw, db)
+
+
+def test_compact_is_bitwise_repeatable():
+    """No atomics, and the race screen of the re-timed dW pipeline (node records three steps ahead, row numbers read
+    back from LDS): 40 launches of forward + backward on one ragged batch give the same bits."""
+    hidden, weight, bias, labels, al, ll = make_inputs(6, 90, 14, 1304, 512, torch.bfloat16, seed=31)
+    n = len(host_rowmap(al, ll, 90, 15))
+    first = None
+    for i in range(40):
+        st, logits, costs, ws, cws = forward_compact(hidden, weight, bias, labels, al, ll, 1408, n + 11)
+        assert st == 0
+        st, dh, dw, db = backward_compact(hidden, weight, logits, 1408, n + 11, labels, al, ll, ws, cws, [1.0], 0, 1.0)
+        assert st == 0
+        got = (logits[:n, :1304].clone(), costs, dh, dw, db)
+        if first is None:
+            first = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, got)), f"launch {i} differs"
