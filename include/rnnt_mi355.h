@@ -315,6 +315,34 @@ rnntStatus_t rnnt_joint_loss_backward_compact(const void *hidden, const void *we
                                               void *backward_workspace, rnntOptions options);
 
 /*
+ * ---- the loss itself on logits kept in the compacted node order (for the same ragged batches) --------------------
+ * The operator the reference calls (/root/reference/src/rnnt/model.py:116) takes the logits of every row of the
+ * [B, maxT, U1] tensor and ignores those outside the lattices; a caller that produces the logits itself (the joint's
+ * output projection as a library GEMM: fp32 training, the reference's own precision) need not produce them.  These
+ * calls are rnnt_forward / rnnt_backward on `acts` [acts_rows, V] holding one row per lattice NODE in the compacted
+ * order above: utterance by utterance, frame by frame, label position fastest.  rnnt_compact_rows writes the map from
+ * node number to tensor row (with which the caller gathers the hidden vectors it projects: row rowmap[k] of
+ * hidden [B * maxT * U1, H] gives node k) — on the device, from the two length tensors.  Costs are those of
+ * rnnt_forward on the padded tensor bit for bit; grads [acts_rows, V] holds the rows of rnnt_backward's gradient that
+ * are nodes, bit for bit (rows of logits that are whole 128-byte lines and longer than 2 KiB; others start at another offset inside a line
+ * in the two layouts, which changes the order of a row's sum of exponentials: last-bit differences of the log-sum),
+ * and no zeros for padding are ever written (on a batch cut like BASELINE config 3 two thirds of
+ * rnnt_backward's bytes are such zeros).  acts_rows: rows the two buffers hold, >= the number of nodes (an upper bound
+ * known on the host; a smaller buffer gives NaN costs for the utterances it cuts, nothing is read or written past it).
+ * rnnt_compact_rows: `capacity` = entries of rowmap; scratch = 16 * (minibatch + 1) bytes, 16-byte aligned;
+ * minibatch * maxT * maxU must fit 31 bits.  Workspace, options, reduction, grad_out as rnnt_forward / rnnt_backward.
+ */
+rnntStatus_t rnnt_compact_rows(const int *act_lens, const int *label_lens, int minibatch, int maxT, int maxU,
+                               long long capacity, int *rowmap, void *scratch, void *stream);
+rnntStatus_t rnnt_forward_compact(const void *acts, long long acts_rows, const int *labels, const int *act_lens,
+                                  const int *label_lens, int alphabet_size, int minibatch, float *costs, float *loss_out,
+                                  int reduction, void *workspace, rnntOptions options);
+rnntStatus_t rnnt_backward_compact(const void *acts, void *grads, long long acts_rows, const int *labels,
+                                   const int *act_lens, const int *label_lens, int alphabet_size, int minibatch,
+                                   const float *grad_out, int grad_out_stride, float grad_scale, const void *workspace,
+                                   rnntOptions options);
+
+/*
  * ---- greedy decoding --------------------------------------------------------
  * out[r] = first index of the maximum of row r of x[rows, V] (a NaN counts as the maximum: torch.argmax's
  * conventions).  Replaces the per-frame softmax -> argmax of the reference's greedy loop

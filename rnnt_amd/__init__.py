@@ -16,8 +16,9 @@ from .parallel import (ShardedRNNTLoss, all_reduce_gradients, balanced_assignmen
                        shard_batch)
 from .train_step import GuardedStep  # noqa: F401
 from .fused import FusedJointLoss, count_lattice_nodes, fused_joint_loss  # noqa: F401
+from .compact import compact_rowmap, rnnt_loss_compact  # noqa: F401
 
 __all__ = ["RNNTLoss", "rnnt_loss", "certify_inputs", "ShardedRNNTLoss", "shard_bounds", "shard_batch",
            "balanced_assignment", "all_reduce_gradients", "JointNet", "joint_hidden", "greedy_decode", "greedy_search_batch", "row_argmax",
-           "row_max_logp", "GuardedStep", "FusedJointLoss", "fused_joint_loss", "count_lattice_nodes", "set_binding", "get_binding"]
+           "row_max_logp", "GuardedStep", "FusedJointLoss", "fused_joint_loss", "count_lattice_nodes", "compact_rowmap", "rnnt_loss_compact", "set_binding", "get_binding"]
 __version__ = "0.2.0"

@@ -46,6 +46,9 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_loss_forward_compact",
     "rnnt_joint_loss_backward_compact_workspace_size",
     "rnnt_joint_loss_backward_compact",
+    "rnnt_compact_rows",
+    "rnnt_forward_compact",
+    "rnnt_backward_compact",
     "rnnt_joint_hidden_forward",
     "rnnt_joint_hidden_workspace_size",
     "rnnt_joint_hidden_backward",
@@ -157,6 +160,15 @@ def load() -> ctypes.CDLL:
                                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int,
                                                          ctypes.c_float, vp, ctypes.c_int, vp, fp, vp, vp, vp, RnntOptions]
         lib.rnnt_joint_loss_backward_compact.restype = ctypes.c_int
+        lib.rnnt_compact_rows.argtypes = [ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, vp, vp,
+                                          ctypes.c_void_p]
+        lib.rnnt_compact_rows.restype = ctypes.c_int
+        lib.rnnt_forward_compact.argtypes = [vp, ctypes.c_longlong, ip, ip, ip, ctypes.c_int, ctypes.c_int, fp, fp,
+                                             ctypes.c_int, vp, RnntOptions]
+        lib.rnnt_forward_compact.restype = ctypes.c_int
+        lib.rnnt_backward_compact.argtypes = [vp, vp, ctypes.c_longlong, ip, ip, ip, ctypes.c_int, ctypes.c_int, fp,
+                                              ctypes.c_int, ctypes.c_float, vp, RnntOptions]
+        lib.rnnt_backward_compact.restype = ctypes.c_int
         lib.rnnt_joint_hidden_forward.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.rnnt_joint_hidden_forward.restype = ctypes.c_int

@@ -556,28 +556,6 @@ __global__ __launch_bounds__(256) void rnnt_fused_merge(const float2 *__restrict
     }
 }
 
-// rowmap[k] = tensor row of compacted node k (lattice.h: Compact), from the spans rnnt_node_spans made of the two
-// length tensors; one thread per row of the [B, maxT, U1] tensor.  A node past `cap` (the caller's logits buffer
-// holds fewer rows than there are nodes) cannot be computed: its lattice entries are set to NaN, so that its
-// utterance's cost comes out NaN instead of being formed from whatever the workspace held.
-__global__ __launch_bounds__(256) void rnnt_compact_rows(int *__restrict__ rowmap, Lattice L, int maxT, int U1,
-                                                         long long rows, long long cap) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const RowCoord c = decode_row(r, maxT, U1);
-    const NodeSpan s = L.spans[c.b];
-    if (c.t >= s.Tb || c.u >= s.Ub1) return;  // padding (an utterance whose lengths do not fit has Tb = 0)
-    const long long k = s.first + (long long)c.t * s.Ub1 + c.u;
-    if (k < cap) {
-        rowmap[k] = (int)r;
-        return;
-    }
-    const size_t o = skew_index(c.b, c.t, c.u, L.ND, L.US);
-    const float nan = __builtin_nanf("");
-    L.ml[o] = make_float2(nan, nan);
-    L.lp[o] = make_float2(nan, nan);
-}
-
 // Compute units of the current device (the size of one round of workgroups: the kernel runs one per CU).
 int compute_units() {
     static std::atomic<int> cached[64];
@@ -604,11 +582,9 @@ rnntStatus_t launch_fused(const void *hidden, const void *weight, const float *b
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const Compact cm = {rowmap, L.spans, B};
     if (rowmap) {
-        if (tensor_rows > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;  // rows are numbered with 32 bits
-        const rnntStatus_t s = launch_node_spans(act_lens, label_lens, B, L, o);
+        rnntStatus_t s = launch_node_spans(act_lens, label_lens, B, L, o);
+        if (s == RNNT_STATUS_SUCCESS) s = launch_compact_rows(rowmap, L, B, rows, o);  // (rows numbered with 32 bits)
         if (s != RNNT_STATUS_SUCCESS) return s;
-        hipLaunchKernelGGL(rnnt_compact_rows, dim3((unsigned)((tensor_rows + 255) / 256)), dim3(256), 0, st, rowmap, L,
-                           o.maxT, o.maxU, tensor_rows, rows);
     }
     // One workgroup per CU at a time: `grid` row tiles take ceil(grid / CUs) rounds, and a last round with few
     // tiles costs as much as a full one (config 2: 2050 tiles on 256 CUs = 8 rounds + 2 tiles, +11 %).  The

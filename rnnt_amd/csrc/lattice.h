@@ -135,5 +135,7 @@ rnntStatus_t launch_lattice_and_costs(const int *act_lens, const int *label_lens
 Lattice carve_workspace(void *ws, int maxT, int maxU, int B);
 // spans[b] = {first compacted node, T_b, U_b + 1}, spans[B].first = the number of nodes (rnnt_node_spans)
 rnntStatus_t launch_node_spans(const int *act_lens, const int *label_lens, int B, const Lattice &L, const rnntOptions &o);
+// rowmap[k] = tensor row of compacted node k (rowmap may be null); nodes from `cap` on get NaN lattice entries
+rnntStatus_t launch_compact_rows(int *rowmap, const Lattice &L, int B, long long cap, const rnntOptions &o);
 
 }  // namespace rnnt_mi355_detail

@@ -198,6 +198,31 @@ __global__ __launch_bounds__(64) void rnnt_node_spans(const int *__restrict__ ac
     }
 }
 
+// rowmap[k] = row (b * maxT + t) * U1 + u of the [B, maxT, U1] tensor of compacted node k (lattice.h: Compact), from
+// the spans above; one thread per row of the tensor.  A node past `cap` (the caller's buffer of per-node rows holds
+// fewer rows than there are nodes) cannot be computed: its lattice entries are set to NaN (where the planes are given),
+// so that its utterance's cost comes out NaN instead of being formed from whatever the workspace held.
+__global__ __launch_bounds__(256) void rnnt_compact_rows_kernel(int *__restrict__ rowmap, const NodeSpan *__restrict__ spans,
+                                                                float2 *__restrict__ ml, float2 *__restrict__ lp, int ND,
+                                                                int US, int maxT, int U1, long long rows, long long cap) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const RowCoord c = decode_row(r, maxT, U1);
+    const NodeSpan s = spans[c.b];
+    if (c.t >= s.Tb || c.u >= s.Ub1) return;  // padding (an utterance whose lengths do not fit has Tb = 0)
+    const long long k = s.first + (long long)c.t * s.Ub1 + c.u;
+    if (k < cap) {
+        if (rowmap) rowmap[k] = (int)r;
+        return;
+    }
+    if (ml) {
+        const size_t o = skew_index(c.b, c.t, c.u, ND, US);
+        const float nan = __builtin_nanf("");
+        ml[o] = make_float2(nan, nan);
+        lp[o] = make_float2(nan, nan);
+    }
+}
+
 struct Node {
     int b, t, u;  // position
     int Tb, Ub;   // lengths of its utterance
@@ -238,7 +263,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
                                                    const int *__restrict__ act_lens,
                                                    const int *__restrict__ label_lens, Lattice L,
                                                    int maxT, int U1, int V, int blank,
-                                                   long long total_rows, int B) {
+                                                   long long total_rows, int B, long long compact_rows) {
     constexpr int EPC = DT::EPC;
     constexpr int WPB = 4;          // waves per workgroup (host launches 256 threads)
     constexpr int RPB = WPB / WPR;  // nodes per workgroup
@@ -249,7 +274,8 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
     const int seg = wave - rib * WPR;
     // !MIS: host guarantees V % EPC == 0, 16-byte aligned rows and V/EPC <= WPR*NCH*64 - 7
     // nodes inside the lattices (a scalar load: the surplus workgroups of a ragged batch leave at once)
-    const long long total = min(L.spans[B].first, total_rows);
+    // compact_rows > 0: `acts` holds one row per NODE, in this order (rnnt_forward_compact), that many rows
+    const long long total = min(min(L.spans[B].first, total_rows), compact_rows ? compact_rows : total_rows);
     const long long ngroups = (total + RPB - 1) / RPB;
     const long long per_b = (long long)maxT * U1;
 
@@ -259,7 +285,7 @@ void rnnt_k1_lse(const typename DT::elem *__restrict__ acts,
         if (WPR == 1 && !valid) break;
         const Node c = find_node(L.spans, B, valid ? k : 0, per_b, lane);
         const int Ub = c.Ub;
-        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
+        const long long r = compact_rows ? (valid ? k : 0) : ((long long)c.b * maxT + c.t) * U1 + c.u;
 
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
@@ -530,7 +556,7 @@ template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
     const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
     const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-    int V, int blank, long long total_rows, int B) {
+    int V, int blank, long long total_rows, int B, long long compact_rows) {
     constexpr int EPC = DT::EPC;
     constexpr int UNR = 8;
     __shared__ float red_m[4], red_s[4];
@@ -540,11 +566,11 @@ __global__ __launch_bounds__(256) void rnnt_k1_lse_wide(
     auto safe = [](float m) { return (m == -INFINITY || m == INFINITY) ? 0.0f : m; };  // as rnnt_k1_lse
 
     const long long per_b = (long long)maxT * U1;
-    const long long total = min(L.spans[B].first, total_rows);
+    const long long total = min(min(L.spans[B].first, total_rows), compact_rows ? compact_rows : total_rows);
     for (long long k = blockIdx.x; k < total; k += gridDim.x) {  // host launches one workgroup per node of the full tensor
         const Node c = find_node(L.spans, B, k, per_b, lane);
         const int Ub = c.Ub;
-        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
+        const long long r = compact_rows ? k : ((long long)c.b * maxT + c.t) * U1 + c.u;
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         const u32x4 *row4 = reinterpret_cast<const u32x4 *>(row);
 
@@ -613,16 +639,16 @@ template <typename DT>
 __global__ __launch_bounds__(256) void rnnt_k1_lse_generic(
     const typename DT::elem *__restrict__ acts, const int *__restrict__ labels,
     const int *__restrict__ act_lens, const int *__restrict__ label_lens, Lattice L, int maxT, int U1,
-    int V, int blank, long long total_rows, int B) {
+    int V, int blank, long long total_rows, int B, long long compact_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long per_b = (long long)maxT * U1;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    const long long total = min(L.spans[B].first, total_rows);
+    const long long total = min(min(L.spans[B].first, total_rows), compact_rows ? compact_rows : total_rows);
     for (long long k = wave0; k < total; k += nwaves) {
         const Node c = find_node(L.spans, B, k, per_b, lane);
         const int Ub = c.Ub;
-        const long long r = ((long long)c.b * maxT + c.t) * U1 + c.u;
+        const long long r = compact_rows ? k : ((long long)c.b * maxT + c.t) * U1 + c.u;
         const typename DT::elem *row = acts + (size_t)r * (size_t)V;
         float m = -INFINITY;
         for (int v = lane; v < V; v += kWave) m = fmaxf(m, DT::to_float(row[v]));
@@ -970,18 +996,30 @@ void rnnt_k3_grad(
     const int *__restrict__ labels, const int *__restrict__ act_lens,
     const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
     int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows,
-    int nseg) {
+    int nseg, int B, long long compact_rows) {
     constexpr int EPC = DT::EPC;
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    const long long nitems = total_rows * nseg;  // a work item = NCH*64 consecutive chunks of one node
+    // compact_rows > 0 (rnnt_backward_compact): acts and grads hold one row per NODE, in the compacted order K1 walks
+    // (rnnt_node_spans); rows are then nodes, found as K1 finds them, and nothing outside the lattices exists
+    const long long nrows = compact_rows ? min(min(L.spans[B].first, total_rows), compact_rows) : total_rows;
+    const long long nitems = nrows * nseg;  // a work item = NCH*64 consecutive chunks of one node
+    const long long per_b = (long long)maxT * U1;
 
     for (long long wi = wave0; wi < nitems; wi += nwaves) {  // host launches one wave per item
         const long long r = wi / nseg;
-        const RowCoord c = decode_row(r, maxT, U1);
-        const int Tb = act_lens[c.b];
-        const int Ub = label_lens[c.b];
+        RowCoord c;
+        int Tb, Ub;
+        if (compact_rows) {  // (kernel-uniform)
+            const Node nd = find_node(L.spans, B, r, per_b, lane);
+            c.b = nd.b, c.t = nd.t, c.u = nd.u;
+            Tb = nd.Tb, Ub = nd.Ub;
+        } else {
+            c = decode_row(r, maxT, U1);
+            Tb = act_lens[c.b];
+            Ub = label_lens[c.b];
+        }
         // MIS: rows are not 16-byte aligned (host guarantees acts and grads share the misalignment);
         // `shift` elements of the previous row sit in chunk 0, see mask_outside_row
         typename DT::elem *orow = grads + (size_t)r * (size_t)V;
@@ -1171,14 +1209,25 @@ __global__ __launch_bounds__(1024) void rnnt_k3_grad_generic(
     const typename DT::elem *__restrict__ acts, typename DT::elem *__restrict__ grads,
     const int *__restrict__ labels, const int *__restrict__ act_lens,
     const int *__restrict__ label_lens, Lattice L, const float *__restrict__ grad_out,
-    int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows) {
+    int grad_out_stride, float grad_scale, int maxT, int U1, int V, int blank, long long total_rows, int B,
+    long long compact_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: row arithmetic on the scalar unit
     const long long nwaves = (long long)gridDim.x * (blockDim.x / kWave);
-    for (long long r = wave0; r < total_rows; r += nwaves) {
-        const RowCoord c = decode_row(r, maxT, U1);
-        const int Tb = act_lens[c.b];
-        const int Ub = label_lens[c.b];
+    const long long nrows = compact_rows ? min(min(L.spans[B].first, total_rows), compact_rows) : total_rows;  // as rnnt_k3_grad
+    const long long per_b = (long long)maxT * U1;
+    for (long long r = wave0; r < nrows; r += nwaves) {
+        RowCoord c;
+        int Tb, Ub;
+        if (compact_rows) {
+            const Node nd = find_node(L.spans, B, r, per_b, lane);
+            c.b = nd.b, c.t = nd.t, c.u = nd.u;
+            Tb = nd.Tb, Ub = nd.Ub;
+        } else {
+            c = decode_row(r, maxT, U1);
+            Tb = act_lens[c.b];
+            Ub = label_lens[c.b];
+        }
         typename DT::elem *out = grads + (size_t)r * (size_t)V;
         if (!lens_ok(Tb, Ub, maxT, U1) || c.t >= Tb || c.u > Ub) {
             for (int v = lane; v < V; v += kWave) out[v] = DT::from_float(0.0f);
@@ -1333,14 +1382,15 @@ inline int small_shape(int V, int dtype, bool mis, int max_shape, int maxT) {
 
 template <typename DT>
 rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens, const int *label_lens,
-                       int V, int B, const Lattice &L, const rnntOptions &o) {
+                       int V, int B, const Lattice &L, const rnntOptions &o, long long compact_rows = 0) {
     typedef typename DT::elem E;
     const long long rows = (long long)B * o.maxT * o.maxU;
     const int block = 256;
     hipStream_t st = static_cast<hipStream_t>(o.stream);
     const bool mis = V % DT::EPC != 0 || reinterpret_cast<uintptr_t>(acts) % 16 != 0;
     const int shape = small_shape(V, o.dtype, mis, 5, o.maxT);
-    if (shape >= 0) {
+    // (the small-row kernels walk the tensor in memory order: a compacted layout takes the one-wave-per-node kernels)
+    if (shape >= 0 && !compact_rows) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, block);
         switch (shape) {
@@ -1363,10 +1413,11 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
     // every other K1 walks the compacted node order (rnnt_node_spans above)
     hipLaunchKernelGGL(rnnt_node_spans, dim3(1), dim3(kWave), 0, st, act_lens, label_lens, B, o.maxT, o.maxU, L.spans);
     const Tile t = pick_tile(acts, nullptr, V, o.dtype, 4);
-    int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
+    const long long grid_rows = compact_rows && compact_rows < rows ? compact_rows : rows;  // (one wave per row of `acts`)
+    int grid = stream_grid(grid_rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K1_GRID", 0);
     if (g > 0) grid = g;
-#define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows, B
+#define K1_ARGS static_cast<const E *>(acts), labels, act_lens, label_lens, L, o.maxT, o.maxU, V, o.blank_label, rows, B, compact_rows
 #define K1_LAUNCH(N, W, M) hipLaunchKernelGGL((rnnt_k1_lse<DT, N, W, M>), dim3(grid), dim3(block), 0, st, K1_ARGS)
 // several waves per node only occur with 9+ chunks per lane (pick_tile): the others are not instantiated
 #define CASE(N)                                                                                        \
@@ -1384,7 +1435,7 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
         FOR_EACH_NCH(CASE)
         default:
             if (vectorisable) {  // row longer than 4 waves hold: one workgroup per node, single streaming pass
-                const int wgrid = g > 0 ? g : (int)(rows > 0x7fffffffLL ? 0x7fffffffLL : rows);
+                const int wgrid = g > 0 ? g : (int)(grid_rows > 0x7fffffffLL ? 0x7fffffffLL : grid_rows);
                 hipLaunchKernelGGL((rnnt_k1_lse_wide<DT>), dim3(wgrid), dim3(block), 0, st, K1_ARGS);
             } else {
                 hipLaunchKernelGGL((rnnt_k1_lse_generic<DT>), dim3(grid), dim3(block), 0, st, K1_ARGS);
@@ -1403,7 +1454,7 @@ rnntStatus_t launch_k1(const void *acts, const int *labels, const int *act_lens,
 template <typename DT>
 rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const int *act_lens,
                        const int *label_lens, int V, int B, const float *grad_out, int grad_out_stride,
-                       float grad_scale, const Lattice &L, const rnntOptions &o) {
+                       float grad_scale, const Lattice &L, const rnntOptions &o, long long compact_rows = 0) {
     typedef typename DT::elem E;
     const long long rows = (long long)B * o.maxT * o.maxU;
     const int block = tuning_knob("RNNT_K3_BLOCK", 512);  // 8 nodes per workgroup: 3.14 -> 3.04 ms vs 256
@@ -1412,7 +1463,7 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
     // 16 chunks per lane (rows of 64..128 chunks) cost K3 its occupancy: V=512 fp32 1.58 ms against 1.44 ms
     // with one wave per node, so K3 stops one shape earlier than K1 (0.83 against 1.04 ms there)
     const int shape = small_shape(V, o.dtype, mis, 4, o.maxT);
-    if (shape >= 0 && reinterpret_cast<uintptr_t>(acts) % 16 == reinterpret_cast<uintptr_t>(grads) % 16) {
+    if (shape >= 0 && !compact_rows && reinterpret_cast<uintptr_t>(acts) % 16 == reinterpret_cast<uintptr_t>(grads) % 16) {
         const long long iters = (rows + kSmallRowsPerWave[shape] - 1) / kSmallRowsPerWave[shape];
         const int sgrid = stream_grid(iters, 256);
         switch (shape) {
@@ -1429,7 +1480,8 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
         return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
     }
     const Tile t = pick_tile(acts, grads, V, o.dtype, 1 << 20, true);
-    int grid = stream_grid(rows * (t.nseg ? t.nseg : 1), block);
+    const long long grid_rows = compact_rows && compact_rows < rows ? compact_rows : rows;
+    int grid = stream_grid(grid_rows * (t.nseg ? t.nseg : 1), block);
     const int g = tuning_knob("RNNT_K3_GRID", 0);
     if (g > 0) grid = g;
     const int lds = tuning_knob("RNNT_K3_LDS", 0);  // unused dynamic LDS: caps workgroups per CU
@@ -1437,14 +1489,14 @@ rnntStatus_t launch_k3(const void *acts, void *grads, const int *labels, const i
 #define CASE(N)                                                                                       \
     case N:                                                                                           \
         if (t.mis)                                                                                    \
-            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, true>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg);  \
+            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, true>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg, B, compact_rows);  \
         else                                                                                          \
-            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, false>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg); \
+            hipLaunchKernelGGL((rnnt_k3_grad<DT, N, false>), dim3(grid), dim3(block), lds, st, K3_ARGS, t.nseg, B, compact_rows); \
         break;
         FOR_EACH_NCH_K3(CASE)
 #undef CASE
         default:
-            hipLaunchKernelGGL((rnnt_k3_grad_generic<DT>), dim3(grid), dim3(block), 0, st, K3_ARGS);
+            hipLaunchKernelGGL((rnnt_k3_grad_generic<DT>), dim3(grid), dim3(block), 0, st, K3_ARGS, B, compact_rows);
     }
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
@@ -1496,6 +1548,13 @@ Lattice carve_workspace(void *ws, int maxT, int maxU, int B) { return carve(ws, 
 rnntStatus_t launch_node_spans(const int *act_lens, const int *label_lens, int B, const Lattice &L, const rnntOptions &o) {
     hipLaunchKernelGGL(rnnt_node_spans, dim3(1), dim3(kWave), 0, static_cast<hipStream_t>(o.stream), act_lens, label_lens,
                        B, o.maxT, o.maxU, L.spans);
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
+rnntStatus_t launch_compact_rows(int *rowmap, const Lattice &L, int B, long long cap, const rnntOptions &o) {
+    const long long rows = (long long)B * o.maxT * o.maxU;
+    if (rows > 0x7fffffffLL) return RNNT_STATUS_INVALID_VALUE;  // rows are numbered with 32 bits
+    hipLaunchKernelGGL(rnnt_compact_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(o.stream), rowmap, L.spans, L.ml, L.lp, L.ND, L.US, o.maxT, o.maxU, rows, cap);
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 }  // namespace rnnt_mi355_detail
@@ -1579,6 +1638,78 @@ rnntStatus_t rnnt_backward(const void *acts, void *grads, const int *labels, con
         default:
             s = launch_k3<F16>(acts, grads, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
                                grad_out_stride, grad_scale, w, options);
+    }
+    if (s != RNNT_STATUS_SUCCESS) return s;
+    record(options, 1);
+    return RNNT_STATUS_SUCCESS;
+}
+
+// ---- the three passes on logits kept in the COMPACTED node order (one row per lattice node; include/rnnt_mi355.h) ----
+rnntStatus_t rnnt_compact_rows(const int *act_lens, const int *label_lens, int minibatch, int maxT, int maxU,
+                               long long capacity, int *rowmap, void *scratch, void *stream) {
+    if (!act_lens || !label_lens || !rowmap || !scratch || minibatch <= 0 || maxT <= 0 || maxU <= 0 || capacity <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (reinterpret_cast<uintptr_t>(scratch) % 16 != 0 || (long long)minibatch * maxT * maxU > 0x7fffffffLL)
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NodeSpan *spans = static_cast<NodeSpan *>(scratch);
+    const long long rows = (long long)minibatch * maxT * maxU;
+    hipLaunchKernelGGL(rnnt_node_spans, dim3(1), dim3(kWave), 0, st, act_lens, label_lens, minibatch, maxT, maxU, spans);
+    hipLaunchKernelGGL(rnnt_compact_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rowmap, spans,
+                       static_cast<float2 *>(nullptr), static_cast<float2 *>(nullptr), 0, 0, maxT, maxU, rows, capacity);
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
+
+rnntStatus_t rnnt_forward_compact(const void *acts, long long acts_rows, const int *labels, const int *act_lens,
+                                  const int *label_lens, int alphabet_size, int minibatch, float *costs, float *loss_out,
+                                  int reduction, void *workspace, rnntOptions options) {
+    if (!check_common(acts, labels, act_lens, label_lens, alphabet_size, minibatch, workspace, options) || !costs ||
+        acts_rows <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (reduction < RNNT_REDUCTION_NONE || reduction > RNNT_REDUCTION_SUM) return RNNT_STATUS_INVALID_VALUE;
+    const Lattice w = carve(workspace, options.maxT, options.maxU, minibatch);
+    record(options, 0);
+    rnntStatus_t s;
+    switch (options.dtype) {
+        case RNNT_DTYPE_F32:
+            s = launch_k1<F32>(acts, labels, act_lens, label_lens, alphabet_size, minibatch, w, options, acts_rows);
+            break;
+        case RNNT_DTYPE_BF16:
+            s = launch_k1<BF16>(acts, labels, act_lens, label_lens, alphabet_size, minibatch, w, options, acts_rows);
+            break;
+        default:
+            s = launch_k1<F16>(acts, labels, act_lens, label_lens, alphabet_size, minibatch, w, options, acts_rows);
+    }
+    if (s != RNNT_STATUS_SUCCESS) return s;
+    // nodes past acts_rows (a buffer smaller than the lattices): NaN lattice entries, hence NaN costs
+    s = rnnt_mi355_detail::launch_compact_rows(nullptr, w, minibatch, acts_rows, options);
+    if (s != RNNT_STATUS_SUCCESS) return s;
+    return launch_lattice_and_costs(act_lens, label_lens, minibatch, costs, loss_out, reduction, w, options);
+}
+
+rnntStatus_t rnnt_backward_compact(const void *acts, void *grads, long long acts_rows, const int *labels,
+                                   const int *act_lens, const int *label_lens, int alphabet_size, int minibatch,
+                                   const float *grad_out, int grad_out_stride, float grad_scale, const void *workspace,
+                                   rnntOptions options) {
+    if (!check_common(acts, labels, act_lens, label_lens, alphabet_size, minibatch, workspace, options) || !grads ||
+        acts_rows <= 0)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (grad_out_stride < 0) return RNNT_STATUS_INVALID_VALUE;
+    const Lattice w = carve(const_cast<void *>(workspace), options.maxT, options.maxU, minibatch);
+    record(options, 0);
+    rnntStatus_t s;
+    switch (options.dtype) {
+        case RNNT_DTYPE_F32:
+            s = launch_k3<F32>(acts, grads, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
+                               grad_out_stride, grad_scale, w, options, acts_rows);
+            break;
+        case RNNT_DTYPE_BF16:
+            s = launch_k3<BF16>(acts, grads, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
+                                grad_out_stride, grad_scale, w, options, acts_rows);
+            break;
+        default:
+            s = launch_k3<F16>(acts, grads, labels, act_lens, label_lens, alphabet_size, minibatch, grad_out,
+                               grad_out_stride, grad_scale, w, options, acts_rows);
     }
     if (s != RNNT_STATUS_SUCCESS) return s;
     record(options, 1);

@@ -174,14 +174,19 @@ def fused_joint_loss_skips_padding(hidden, weight, min_nodes=DEFAULT_MIN_NODES) 
             and min_nodes <= rows < 2 ** 31)
 
 
-def count_lattice_nodes(act_lens, label_lens) -> int:
+def count_lattice_nodes(act_lens, label_lens, maxT=None, maxU1=None) -> int:
     """Sum of ``T_b * (U_b + 1)`` over the batch from HOST copies of the two length tensors (any integer sequences or
     CPU tensors): the ``valid_nodes`` argument of :func:`fused_joint_loss`.  The reference has both on the host when
     it calls the loss (``enc_output_lengths`` comes out of ``pad_packed_sequence``, ``tokens_length`` out of the data
-    loader: /root/reference/src/rnnt/model.py:104-116), so the count costs no device round trip there."""
-    t = torch.as_tensor(act_lens, device="cpu").to(torch.int64).clamp_min(0)
-    u = torch.as_tensor(label_lens, device="cpu").to(torch.int64).clamp_min(0)
-    return int((t * (u + 1)).sum())
+    loader: /root/reference/src/rnnt/model.py:104-116), so the count costs no device round trip there.
+    With ``maxT`` / ``maxU1`` (the lattice tensor's frames and columns) utterances whose lengths do not fit are left
+    out, as the kernels leave them out: the count is then exact, not an upper bound."""
+    t = torch.as_tensor(act_lens, device="cpu").to(torch.int64)
+    u = torch.as_tensor(label_lens, device="cpu").to(torch.int64)
+    n = t.clamp_min(0) * (u.clamp_min(0) + 1)
+    if maxT is not None and maxU1 is not None:
+        n = n * ((t >= 1) & (t <= int(maxT)) & (u >= 0) & (u < int(maxU1)))
+    return int(n.sum())
 
 
 def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0, reduction="mean",

@@ -113,6 +113,12 @@ def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, 
     return _JointHidden.apply(enc_proj, dec_proj, act_lens, label_lens)
 
 
+# JointNet.transducer_loss, lengths known on the host: a batch with fewer lattice nodes than this share of the rows of
+# its [B, T, U+1] tensor takes the compacted route (gather + GEMM over the nodes + rnnt_loss_compact); a fuller one is
+# not worth the gather.
+COMPACT_BELOW = 0.9
+
+
 class JointNet(nn.Module):
     """Drop-in for the reference's ``JointNet`` (model.py:9-63); see the module docstring."""
 
@@ -160,7 +166,7 @@ class JointNet(nn.Module):
         if not act_lens.is_cuda and not label_lens.is_cuda:
             from .fused import count_lattice_nodes
 
-            valid_nodes = count_lattice_nodes(act_lens, label_lens)
+            valid_nodes = count_lattice_nodes(act_lens, label_lens, enc_state.size(1), dec_state.size(1))
         act_lens = act_lens.to(device=enc_state.device, dtype=torch.int32)
         label_lens = label_lens.to(device=enc_state.device, dtype=torch.int32)
         if enc_state.dtype in (torch.bfloat16, torch.float16):
@@ -175,6 +181,18 @@ class JointNet(nn.Module):
                 hidden = self.hidden(enc_state, dec_state, *((act_lens, label_lens) if ragged else ()))
                 return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction,
                                         valid_nodes=valid_nodes, zero_padding_grad=not ragged)
+        B, T, U1 = enc_state.size(0), enc_state.size(1), dec_state.size(1)
+        if valid_nodes is not None and 0 < valid_nodes <= COMPACT_BELOW * B * T * U1 and B * T * U1 < 2 ** 31:
+            # fp32 states (the reference's own precision) and the shapes the fused kernels leave to the library: the
+            # projection and the loss's three passes run over the lattice nodes only (rnnt_amd/compact.py) — the two
+            # fp32 GEMMs of the projection's forward and backward are most of this step, and they shrink with the nodes
+            from .compact import compact_rowmap, rnnt_loss_compact
+
+            rowmap = compact_rowmap(act_lens, label_lens, T, U1, valid_nodes)
+            hidden = self.hidden(enc_state, dec_state, act_lens, label_lens)       # rows outside the lattices: untouched
+            nodes = hidden.view(B * T * U1, -1).index_select(0, rowmap.long())     # [n, H]
+            return rnnt_loss_compact(out(nodes), labels, act_lens, label_lens, T, blank=blank, reduction=reduction,
+                                     exact_rows=True)
         hidden = self.hidden(enc_state, dec_state)
         from .loss import rnnt_loss
 
