@@ -167,8 +167,15 @@ class JointNet(nn.Module):
             from .fused import count_lattice_nodes
 
             valid_nodes = count_lattice_nodes(act_lens, label_lens, enc_state.size(1), dec_state.size(1))
-        act_lens = act_lens.to(device=enc_state.device, dtype=torch.int32)
-        label_lens = label_lens.to(device=enc_state.device, dtype=torch.int32)
+        if valid_nodes is not None and enc_state.is_cuda:
+            # one asynchronous copy from pinned memory: `lengths.cuda()` from pageable memory (model.py:109) makes the host
+            # wait for everything queued on the device before it, every step
+            both = torch.stack((act_lens.to(torch.int32), label_lens.to(torch.int32))).pin_memory()
+            both = both.to(enc_state.device, non_blocking=True)
+            act_lens, label_lens = both[0], both[1]
+        else:
+            act_lens = act_lens.to(device=enc_state.device, dtype=torch.int32)
+            label_lens = label_lens.to(device=enc_state.device, dtype=torch.int32)
         if enc_state.dtype in (torch.bfloat16, torch.float16):
             from .fused import SUPPORTED_HIDDEN, fused_joint_loss, fused_joint_loss_skips_padding
 

@@ -249,6 +249,21 @@ def test_jointnet_transducer_loss_never_waits_on_the_host():
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert bool(torch.isfinite(loss).all()) and bool(torch.isfinite(enc.grad.float()).all())
+    # lengths on the host, as the reference has them (model.py:104-111): counted there, sent over by one asynchronous copy
+    # from pinned memory — still no wait; the compacted routes, fused (bf16) and library GEMM + compacted loss (fp32)
+    al_host, ll_host = al.cpu(), ll.cpu()
+    for dtype in (torch.bfloat16, torch.float32):
+        net2 = rnnt_amd.JointNet(He + Hd, H, V).to(DEV).to(dtype)
+        e2, d2 = enc.detach().to(dtype).requires_grad_(True), dec.detach().to(dtype).requires_grad_(True)
+        net2.transducer_loss(e2, d2, labels, al_host, ll_host).backward()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            loss = net2.transducer_loss(e2, d2, labels, al_host, ll_host)
+            loss.backward()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert bool(torch.isfinite(loss).all())
 
 
 def test_joint_hidden_config2_size():
