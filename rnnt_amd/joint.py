@@ -84,6 +84,52 @@ class _JointHidden(torch.autograd.Function):
         return grad_enc, grad_dec, None, None
 
 
+class _Projection(torch.autograd.Function):
+    """``F.linear(x, weight, bias)`` over the rows of ``x`` ``[n, H]`` (fp32), with the weight gradient formed as a
+    split-K product.  ``grad_weight = g^T x`` contracts over n = 10^5 .. 10^6 rows into a ``[V, H]`` result of a few
+    dozen 256 x 256 tiles: as ONE library GEMM it runs on that many workgroups of a 256-CU chip (V = 4232, H = 512,
+    n = 65 773: 4.45 ms = 64 TFLOP/s).  Cut into 32 row ranges as a batched GEMM whose partial products are added in
+    range order it fills the chip: 2.09 ms there, 8.6 -> 6.4 ms at n = 197 944, 18.9 -> 16.9 ms at n = 524 800
+    (profiles/r03_tuning.md §7).  Same sums in another association (fp32 throughout; deterministic)."""
+
+    RANGES = 32
+    MIN_ROWS = 8192
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g, weight)
+        if ctx.needs_input_grad[1]:
+            n, S = g.shape[0], _Projection.RANGES
+            m = n // S
+            if n >= _Projection.MIN_ROWS:
+                gw = torch.bmm(g[:m * S].view(S, m, -1).transpose(1, 2), x[:m * S].view(S, m, -1)).sum(0)
+                if m * S < n:
+                    gw = gw + torch.mm(g[m * S:].t(), x[m * S:])
+            else:
+                gw = torch.mm(g.t(), x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def _project(x, linear):
+    """``linear(x)`` for ``x`` ``[..., H]``; fp32 on the device takes :class:`_Projection`."""
+    if x.dtype is torch.float32 and x.is_cuda and linear.weight.dtype is torch.float32:
+        return _Projection.apply(x.reshape(-1, x.shape[-1]), linear.weight, linear.bias).view(*x.shape[:-1], -1)
+    return linear(x)
+
+
 def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, label_lens=None) -> torch.Tensor:
     """``tanh(enc_proj[:, :, None, :] + dec_proj[:, None, :, :])`` → ``[B, T, U+1, H]`` on the MI355X.
 
@@ -198,12 +244,12 @@ class JointNet(nn.Module):
             rowmap = compact_rowmap(act_lens, label_lens, T, U1, valid_nodes)
             hidden = self.hidden(enc_state, dec_state, act_lens, label_lens)       # rows outside the lattices: untouched
             nodes = hidden.view(B * T * U1, -1).index_select(0, rowmap.long())     # [n, H]
-            return rnnt_loss_compact(out(nodes), labels, act_lens, label_lens, T, blank=blank, reduction=reduction,
-                                     exact_rows=True)
+            return rnnt_loss_compact(_project(nodes, out), labels, act_lens, label_lens, T, blank=blank,
+                                     reduction=reduction, exact_rows=True)
         hidden = self.hidden(enc_state, dec_state)
         from .loss import rnnt_loss
 
-        return rnnt_loss(out(hidden), labels, act_lens, label_lens, blank=blank, reduction=reduction)
+        return rnnt_loss(_project(hidden, out), labels, act_lens, label_lens, blank=blank, reduction=reduction)
 
     def forward(self, enc_state, dec_state, softmax=False):
         if enc_state.dim() != dec_state.dim():
@@ -215,7 +261,7 @@ class JointNet(nn.Module):
             # already unsqueezed by the caller ([B,T,1,He] / [B,1,U+1,Hd]), model.py:46-50
             enc_state, dec_state = enc_state.squeeze(2), dec_state.squeeze(1)
         if enc_state.dim() == 3:
-            joint = self.mlp[2](self.hidden(enc_state, dec_state))     # [B, T, U+1, V]
+            joint = _project(self.hidden(enc_state, dec_state), self.mlp[2])     # [B, T, U+1, V]
         else:
             # evaluation: one frame against one decoder state ([B *] H), model.py:51-54 — a few hundred
             # numbers; greedy/beam decoding is outside this package's scope

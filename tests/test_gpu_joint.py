@@ -294,3 +294,27 @@ def test_joint_hidden_argument_checks():
         rnnt_amd.joint_hidden(e, torch.zeros(2, 4, 8, device=DEV, dtype=torch.bfloat16))
     with pytest.raises(RuntimeError, match="no CPU"):
         rnnt_amd.joint_hidden(e.cpu(), torch.zeros(2, 4, 8))
+
+
+def test_projection_with_split_weight_gradient():
+    """rnnt_amd.joint._Projection (the output projection of the fp32 routes): the weight gradient as 32 partial products
+    over row ranges added in range order, against torch's own Linear backward in float64."""
+    from rnnt_amd.joint import _Projection
+
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for n in (100, 8192, 20011):
+        x = torch.randn(n, 512, device=DEV, generator=g).requires_grad_(True)
+        w = (torch.randn(700, 512, device=DEV, generator=g) * 0.05).requires_grad_(True)
+        b = torch.randn(700, device=DEV, generator=g).requires_grad_(True)
+        go = torch.randn(n, 700, device=DEV, generator=g)
+        y = _Projection.apply(x, w, b)
+        y.backward(go)
+        x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+        y64 = torch.nn.functional.linear(x64, w64, b64)
+        y64.backward(go.double())
+        assert rel_to_max(y.detach().double(), y64.detach()) <= 5e-6
+        for got, ref in ((x.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
+            assert rel_to_max(got.double(), ref) <= 5e-6
+        x3, w3 = x.detach().requires_grad_(True), w.detach().requires_grad_(True)
+        _Projection.apply(x3, w3, b.detach()).backward(go)        # a second run: the same bits (fixed summation order)
+        assert torch.equal(w3.grad, w.grad)
