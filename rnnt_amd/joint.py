@@ -199,7 +199,16 @@ class JointNet(nn.Module):
         ``self.transducer_loss(logits, tokens.int(), output_length, tokens_length.int())`` (model.py:115-116) as one
         call.  16-bit states (bf16/fp16 training): the output projection and the loss run fused
         (``rnnt_amd.FusedJointLoss``: the logits are written once and never read by a softmax pass, their gradient is
-        never written); fp32 states: the projection as a library GEMM and ``rnnt_amd.rnnt_loss`` on its logits."""
+        never written), over the lattice nodes of the batch only (the compacted node order); fp32 states: the
+        projection as a library GEMM and ``rnnt_amd.rnnt_loss`` on its logits.
+
+        ``act_lens`` / ``label_lens`` may be CPU tensors — where the reference has them when it makes this call
+        (``enc_output_lengths``, ``tokens_length``: model.py:104-111).  The lattice nodes are then counted on the host
+        (no device round trip), the lengths go to the device by one asynchronous copy, buffers and launch grids are cut
+        for the nodes, and the fp32 route too skips everything outside the lattices: hidden layer, projection GEMMs and
+        the loss's three passes run on one row per node (``rnnt_amd.rnnt_loss_compact``) — the same costs bit for bit.
+        With device tensors nothing is read back: the fused route still skips the padding (the nodes are numbered on the
+        device), the fp32 route works on the padded tensor."""
         if enc_state.dim() != 3 or dec_state.dim() != 3:
             raise ValueError("transducer_loss takes enc_state [B, T, He] and dec_state [B, U+1, Hd]")
         if self.joint not in ("sum", "concat"):

@@ -1,7 +1,16 @@
-import sqlite3, sys, glob
-for f in sys.argv[1:]:
-    c=sqlite3.connect(f)
-    rows=c.execute("select name, count(*), avg(end-start), sum(end-start) from kernels group by name order by 4 desc limit 22").fetchall()
-    tot=sum(r[3] for r in c.execute("select name, count(*), avg(end-start), sum(end-start) from kernels group by name").fetchall())
-    print(f, "total kernel ms", tot/1e6)
-    for r in rows: print(f"{r[1]:5d} {r[2]/1e3:10.1f} us  {r[3]/1e6:9.2f} ms  {r[0][:100]}")
+#!/usr/bin/env python3
+"""Per-kernel totals of a rocprofv3 run that wrote its default output (a rocpd SQLite database) instead of CSV:
+
+    rocprofv3 --kernel-trace --stats -d out -o name -- python3 tool.py ...      ->  out/name_results.db
+    python tools/rocprof_db_stats.py out/name_results.db [more.db ...]
+
+(`--output-format csv` gives the same table as *_kernel_stats.csv directly; profiles/ holds those.)"""
+import sqlite3
+import sys
+
+for path in sys.argv[1:]:
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, count(*), avg(end-start), sum(end-start) from kernels group by name order by 4 desc").fetchall()
+    print(path, "total kernel ms", sum(r[3] for r in rows) / 1e6)
+    for name, calls, avg, total in rows[:22]:
+        print(f"{calls:5d} {avg / 1e3:10.1f} us  {total / 1e6:9.2f} ms  {name[:100]}")
