@@ -208,12 +208,22 @@ class JointNet(nn.Module):
         for the nodes, and the fp32 route too skips everything outside the lattices: hidden layer, projection GEMMs and
         the loss's three passes run on one row per node (``rnnt_amd.rnnt_loss_compact``) — the same costs bit for bit.
         With device tensors nothing is read back: the fused route still skips the padding (the nodes are numbered on the
-        device), the fp32 route works on the padded tensor."""
+        device), the fp32 route works on the padded tensor.
+
+        Under ``torch.autocast("cuda", dtype=torch.bfloat16 / torch.float16)`` fp32 states and parameters take the
+        16-bit fused route (states and projection weight are cast; gradients arrive in fp32)."""
         if enc_state.dim() != 3 or dec_state.dim() != 3:
             raise ValueError("transducer_loss takes enc_state [B, T, He] and dec_state [B, U+1, Hd]")
         if self.joint not in ("sum", "concat"):
             raise NotImplementedError
         out = self.mlp[2]
+        if enc_state.is_cuda and enc_state.dtype is torch.float32 and torch.is_autocast_enabled("cuda"):
+            # fp32 parameters and states under torch.autocast("cuda", dtype=bf16 / fp16): as a Linear + loss would run
+            # there, the states and (below) the projection's weight go to the 16-bit type and the fused route is taken;
+            # gradients come back in fp32 through the casts
+            amp = torch.get_autocast_dtype("cuda")
+            if amp in (torch.bfloat16, torch.float16):
+                enc_state, dec_state = enc_state.to(amp), dec_state.to(amp)
         # Lengths still on the host (the reference's are: model.py:104-111 moves them to the device for the loss): the
         # number of lattice nodes is counted there, for free, and the fused kernels are cut for the nodes of a ragged
         # batch instead of for the padded tensor; then the lengths go to the device as the reference's do.
@@ -241,7 +251,8 @@ class JointNet(nn.Module):
                 # differentiates, only those rows too
                 ragged = fused_joint_loss_skips_padding(shape, out.weight)
                 hidden = self.hidden(enc_state, dec_state, *((act_lens, label_lens) if ragged else ()))
-                return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction,
+                weight = out.weight if out.weight.dtype is hidden.dtype else out.weight.to(hidden.dtype)   # (autocast)
+                return fused_joint_loss(hidden, weight, out.bias, labels, act_lens, label_lens, blank, reduction,
                                         valid_nodes=valid_nodes, zero_padding_grad=not ragged)
         B, T, U1 = enc_state.size(0), enc_state.size(1), dec_state.size(1)
         if valid_nodes is not None and 0 < valid_nodes <= COMPACT_BELOW * B * T * U1 and B * T * U1 < 2 ** 31:

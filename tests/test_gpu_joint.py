@@ -318,3 +318,47 @@ def test_projection_with_split_weight_gradient():
         x3, w3 = x.detach().requires_grad_(True), w.detach().requires_grad_(True)
         _Projection.apply(x3, w3, b.detach()).backward(go)        # a second run: the same bits (fixed summation order)
         assert torch.equal(w3.grad, w.grad)
+
+
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16])
+def test_transducer_loss_under_autocast_takes_the_fused_route(amp):
+    """fp32 parameters and fp32 states under torch.autocast (mixed-precision training of the reference's fp32 model):
+    `JointNet.transducer_loss` casts the states and the projection's weight and runs the fused 16-bit kernels; loss
+    and fp32 gradients agree with the fp32 route to the 16-bit rounding of states, hidden layer and logits."""
+    import rnnt_amd
+    from cases import make_case
+
+    B, T, U, V = 4, 96, 47, 600                                    # 18 432 rows: above the fused kernels' threshold
+    torch.manual_seed(2)
+    joint = rnnt_amd.JointNet(640, 512, V).to(DEV)
+    _, labels, al, ll = make_case(B, T, U, V, seed=9, ragged=True)
+    lab, al_host, ll_host = torch.from_numpy(labels).to(DEV), torch.from_numpy(al), torch.from_numpy(ll)
+    enc0 = 0.5 * torch.randn(B, T, 320, device=DEV)
+    dec0 = 0.5 * torch.randn(B, U + 1, 320, device=DEV)
+
+    def run(autocast):
+        joint.zero_grad(set_to_none=True)
+        enc, dec = enc0.clone().requires_grad_(True), dec0.clone().requires_grad_(True)
+        if autocast:
+            with torch.autocast("cuda", dtype=amp):
+                loss = joint.transducer_loss(enc, dec, lab, al_host, ll_host)
+        else:
+            loss = joint.transducer_loss(enc, dec, lab, al_host, ll_host)
+        loss.backward()
+        return [loss.detach(), enc.grad, dec.grad] + [p.grad.clone() for p in joint.parameters()]
+
+    import rnnt_amd.fused as fused_mod
+    calls = []
+    orig = fused_mod._FusedJointLossFunction.apply
+    fused_mod._FusedJointLossFunction.apply = lambda *a: (calls.append(a[0].dtype), orig(*a))[1]
+    try:
+        mixed = run(True)
+    finally:
+        fused_mod._FusedJointLossFunction.apply = orig
+    assert calls == [amp]                                          # the fused kernels ran, on 16-bit operands
+    full = run(False)
+    assert all(t.dtype is torch.float32 for t in mixed[1:])        # gradients of fp32 leaves stay fp32
+    tol = 3e-2 if amp is torch.bfloat16 else 6e-3
+    torch.testing.assert_close(mixed[0], full[0], rtol=tol, atol=0)
+    for a, b in zip(mixed[1:], full[1:]):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())

@@ -4,6 +4,7 @@ the reference's formulation in stock torch (repeat / cat / Linear / Tanh / Linea
 rnnt_amd.JointNet + RNNTLoss (two calls) and rnnt_amd.JointNet.transducer_loss (one call).  One JSON line.
 
     python tools/bench_joint_loss.py [--dtype bf16|f16|f32] [--shape B,T,U,V] [--reps 9] [--out file.json] [--ragged SEED]
+                                       [--autocast bf16|f16]
 
 --ragged: utterance lengths as in BASELINE config 3 scaled to the shape (T_b uniform in [T/8, T], U_b in [U/6, U], one
 utterance at (T, U)), kept on the HOST as the reference has them when it calls the loss (model.py:104-111): the one-call
@@ -42,6 +43,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--ragged", type=int, default=None, metavar="SEED")
     ap.add_argument("--only-one-call", action="store_true", help="time JointNet.transducer_loss only (for profiler runs)")
+    ap.add_argument("--autocast", default=None, choices=["bf16", "f16"],
+                    help="run every formulation under torch.autocast of this dtype (use with --dtype f32: fp32 model)")
     args = ap.parse_args()
     import rnnt_amd
 
@@ -66,28 +69,37 @@ def main():
     nodes = rnnt_amd.count_lattice_nodes(al_host, ll_host)
     crit = rnnt_amd.RNNTLoss(check_lengths=False)
 
+    import contextlib
+    amp = {"bf16": torch.bfloat16, "f16": torch.float16, None: None}[args.autocast]
+
+    def cast():
+        return torch.autocast("cuda", dtype=amp) if amp is not None else contextlib.nullcontext()
+
     def clear():
         enc.grad = dec.grad = None
         net.zero_grad(set_to_none=True)
 
     def reference_formulation():  # model.py:46-59 in stock torch, then the loss
         clear()
-        e = enc.unsqueeze(2).repeat(1, 1, U + 1, 1)
-        d = dec.unsqueeze(1).repeat(1, T, 1, 1)
-        logits = net.mlp(torch.cat((e, d), dim=-1))
-        loss = crit(logits, labels, al, ll)
+        with cast():
+            e = enc.unsqueeze(2).repeat(1, 1, U + 1, 1)
+            d = dec.unsqueeze(1).repeat(1, T, 1, 1)
+            logits = net.mlp(torch.cat((e, d), dim=-1))
+            loss = crit(logits, labels, al, ll)
         loss.backward()
         return loss
 
     def two_calls():
         clear()
-        loss = crit(net(enc, dec), labels, al, ll)
+        with cast():
+            loss = crit(net(enc, dec), labels, al, ll)
         loss.backward()
         return loss
 
     def one_call():
         clear()
-        loss = net.transducer_loss(enc, dec, labels, al_host, ll_host)  # (lengths on the host: model.py:104-111)
+        with cast():
+            loss = net.transducer_loss(enc, dec, labels, al_host, ll_host)  # (lengths on the host: model.py:104-111)
         loss.backward()
         return loss
 
@@ -95,7 +107,7 @@ def main():
         print(json.dumps({"lengths": "uniform" if args.ragged is None else f"ragged (seed {args.ragged})", "nodes": nodes,
                           "JointNet.transducer_loss_ms": round(median_ms(one_call, args.reps), 3)}))
         return
-    res = {"shape": dict(B=B, T=T, U=U, V=V, He=He, Hd=Hd, H=H), "dtype": args.dtype,
+    res = {"shape": dict(B=B, T=T, U=U, V=V, He=He, Hd=Hd, H=H), "dtype": args.dtype, "autocast": args.autocast,
            "lengths": "uniform" if args.ragged is None else
                       f"ragged (seed {args.ragged}): {nodes} of {B * T * (U + 1)} rows are lattice nodes",
            "loss": {"reference formulation": float(reference_formulation()), "JointNet + RNNTLoss": float(two_calls()),
