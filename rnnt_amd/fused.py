@@ -202,7 +202,7 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         hidden: ``[B, T, U+1, H]`` bf16 or fp16, contiguous: what ``JointNet``'s ``Tanh`` returns
             (``rnnt_amd.joint_hidden``); ``H`` in ``SUPPORTED_HIDDEN``.
         weight, bias: the parameters of ``Linear(H -> V)`` (``mlp.2`` of the reference's ``JointNet``);
-            weight in ``hidden``'s dtype, ``[V, H]`` contiguous.
+            weight ``[V, H]`` (another floating dtype than ``hidden``'s, e.g. an fp32 parameter under autocast, is cast).
         labels, act_lens, label_lens, blank, reduction: as :func:`rnnt_amd.rnnt_loss`.
         valid_nodes: optional upper bound of the number of lattice nodes ``sum_b T_b (U_b + 1)``, known on the host
             (:func:`count_lattice_nodes`).  The kernels skip the padding of a ragged batch either way (they number
@@ -222,7 +222,9 @@ def fused_joint_loss(hidden, weight, bias, labels, act_lens, label_lens, blank=0
         raise ValueError("fused_joint_loss needs the projection's bias (nn.Linear(bias=True)); pass a zero vector for a "
                          "projection without one")
     if weight.dtype is not hidden.dtype:
-        raise TypeError("weight must have hidden's dtype")
+        if not weight.is_floating_point():
+            raise TypeError("weight must be a floating-point tensor")
+        weight = weight.to(hidden.dtype)  # e.g. an fp32 parameter under autocast: its gradient comes back through the cast
     if hidden.dim() != 4 or weight.dim() != 2 or bias.dim() != 1:
         raise ValueError("hidden must be 4D, weight 2D, bias 1D")
     if not hidden.is_cuda:

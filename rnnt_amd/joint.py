@@ -251,8 +251,8 @@ class JointNet(nn.Module):
                 # differentiates, only those rows too
                 ragged = fused_joint_loss_skips_padding(shape, out.weight)
                 hidden = self.hidden(enc_state, dec_state, *((act_lens, label_lens) if ragged else ()))
-                weight = out.weight if out.weight.dtype is hidden.dtype else out.weight.to(hidden.dtype)   # (autocast)
-                return fused_joint_loss(hidden, weight, out.bias, labels, act_lens, label_lens, blank, reduction,
+                # (an fp32 weight under autocast is cast to the states' type inside)
+                return fused_joint_loss(hidden, out.weight, out.bias, labels, act_lens, label_lens, blank, reduction,
                                         valid_nodes=valid_nodes, zero_padding_grad=not ragged)
         B, T, U1 = enc_state.size(0), enc_state.size(1), dec_state.size(1)
         if valid_nodes is not None and 0 < valid_nodes <= COMPACT_BELOW * B * T * U1 and B * T * U1 < 2 ** 31:

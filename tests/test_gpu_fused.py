@@ -338,3 +338,27 @@ def test_fused_config2_shape_full_size():
     c, _, _ = oracle.rnnt_loss_c(logits[b:b + 1, :Tb, :Ub + 1].float().cpu().numpy(), labels[b:b + 1, :Ub], [Tb], [Ub],
                                  want_grads=False)
     assert abs(float(costs[b]) - c[0]) <= 1e-5 * abs(c[0])
+
+
+def test_module_under_autocast_with_fp32_projection():
+    """`FusedJointLoss` inside torch.autocast with the reference's fp32 `Linear(512 -> V)`: the weight is cast to the
+    hidden layer's 16-bit type, its gradient comes back in fp32 and equals the bf16-weight call's (rounded once)."""
+    import rnnt_amd
+
+    B, T, U, V, H = 3, 50, 9, 333, 256
+    torch.manual_seed(4)
+    proj = torch.nn.Linear(H, V).to(DEV)
+    hidden = torch.tanh(torch.randn(B, T, U + 1, H, device=DEV)).to(torch.bfloat16).requires_grad_(True)
+    _, labels, al, ll = make_case(B, T, U, V, seed=1, ragged=True)
+    lab, ald, lld = (torch.from_numpy(x).to(DEV) for x in (labels, al, ll))
+    crit = rnnt_amd.FusedJointLoss(min_nodes=0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = crit(hidden, proj, lab, ald, lld)
+    loss.backward()
+    assert proj.weight.grad.dtype is torch.float32 and proj.bias.grad.dtype is torch.float32
+    w16 = proj.weight.detach().to(torch.bfloat16).requires_grad_(True)
+    h2 = hidden.detach().clone().requires_grad_(True)
+    loss2 = rnnt_amd.fused_joint_loss(h2, w16, proj.bias.detach(), lab, ald, lld, min_nodes=0)
+    loss2.backward()
+    assert torch.equal(loss.detach(), loss2.detach()) and torch.equal(hidden.grad, h2.grad)
+    assert torch.equal(proj.weight.grad, w16.grad.float())
