@@ -125,7 +125,8 @@ class _Projection(torch.autograd.Function):
 
 def _project(x, linear):
     """``linear(x)`` for ``x`` ``[..., H]``; fp32 on the device takes :class:`_Projection`."""
-    if x.dtype is torch.float32 and x.is_cuda and linear.weight.dtype is torch.float32:
+    if (x.dtype is torch.float32 and x.is_cuda and linear.weight.dtype is torch.float32
+            and not torch.is_autocast_enabled("cuda")):  # (under autocast the library's Linear casts its operands)
         return _Projection.apply(x.reshape(-1, x.shape[-1]), linear.weight, linear.bias).view(*x.shape[:-1], -1)
     return linear(x)
 
