@@ -194,6 +194,24 @@ rnntStatus_t rnnt_joint_hidden_backward_ragged(const void *hidden, const void *g
                                                int T, int U1, int H, rnntDtype_t dtype, void *workspace, void *stream);
 
 /*
+ * The same pair with `hidden` (and `grad_hidden`) in the COMPACTED node order: [hidden_rows, H], one row per lattice
+ * node — utterance by utterance, frame by frame, label position fastest, the order of rnnt_compact_rows and of
+ * rnnt_forward_compact's logits — instead of [B, T, U1, H].  For the caller that projects the nodes only (the
+ * reference's Linear(512 -> V) of model.py:17,59 as a library GEMM over n rows, then rnnt_forward_compact): the hidden
+ * vectors land where that GEMM reads them, without a gather, and their gradients are read from where its backward
+ * leaves them, without a scatter into a zero-filled [B, T, U1, H] tensor.  The node numbering is derived on the device
+ * from the two length tensors.  hidden_rows >= the number of nodes; frames the buffer has no room for are skipped
+ * (forward) / taken as zero gradient (backward).  Same workspace size.
+ */
+rnntStatus_t rnnt_joint_hidden_forward_compact(const void *enc_proj, const void *dec_proj, void *hidden,
+                                               long long hidden_rows, const int *act_lens, const int *label_lens, int B,
+                                               int T, int U1, int H, rnntDtype_t dtype, void *stream);
+rnntStatus_t rnnt_joint_hidden_backward_compact(const void *hidden, const void *grad_hidden, long long hidden_rows,
+                                                void *grad_enc_proj, void *grad_dec_proj, const int *act_lens,
+                                                const int *label_lens, int B, int T, int U1, int H, rnntDtype_t dtype,
+                                                void *workspace, void *stream);
+
+/*
  * ---- the joint's output projection fused with the loss's first pass ----------
  *
  * Replaces the pair  logits = Linear(H -> V)(hidden)  (/root/reference/src/rnnt/model.py:17,59) and the

@@ -54,6 +54,8 @@ EXPORTED_SYMBOLS = (
     "rnnt_joint_hidden_backward",
     "rnnt_joint_hidden_forward_ragged",
     "rnnt_joint_hidden_backward_ragged",
+    "rnnt_joint_hidden_forward_compact",
+    "rnnt_joint_hidden_backward_compact",
     "rnnt_row_argmax",
     "rnnt_row_max_logp",
     "rnnt_event_create",
@@ -184,6 +186,13 @@ def load() -> ctypes.CDLL:
         lib.rnnt_joint_hidden_backward_ragged.argtypes = [vp, vp, vp, vp, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                           ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_joint_hidden_backward_ragged.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_forward_compact.argtypes = [vp, vp, vp, ctypes.c_longlong, ip, ip, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.rnnt_joint_hidden_forward_compact.restype = ctypes.c_int
+        lib.rnnt_joint_hidden_backward_compact.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, ip, ip, ctypes.c_int,
+                                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp,
+                                                           ctypes.c_void_p]
+        lib.rnnt_joint_hidden_backward_compact.restype = ctypes.c_int
         lib.rnnt_row_argmax.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_void_p]
         lib.rnnt_row_argmax.restype = ctypes.c_int
         lib.rnnt_row_max_logp.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_void_p]

@@ -113,6 +113,21 @@ __device__ __forceinline__ float joint_tanh(float x) {
     }
 }
 
+// Compacted layout (rnnt_joint_hidden_*_compact): `hidden` holds one row per lattice NODE, in the order the loss's
+// compacted kernels walk (lattice.h: utterance by utterance, frame by frame, label position fastest; an utterance whose
+// lengths do not fit the tensor has no nodes).  Number of nodes of the utterances before b, the same in every lane.
+__device__ __forceinline__ long long nodes_before(const int *__restrict__ act_lens, const int *__restrict__ label_lens,
+                                                  int b, int T, int U1, int lane) {
+    long long s = 0;
+    for (int i = lane; i < b; i += kWave) {
+        const int Tb = act_lens[i], Ub = label_lens[i];
+        if (Tb >= 1 && Tb <= T && Ub >= 0 && Ub < U1) s += (long long)Tb * (Ub + 1);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: one wave per (b,t); the enc_proj piece stays in registers while u runs over U1
 // grid = (ceil(B*T / kJW), ceil(H / CW)),  CW = 64 * VEC * kJCH columns per tile
@@ -123,7 +138,8 @@ __global__ __launch_bounds__(kJW *kWave) void joint_hidden_fwd(const typename DT
                                                                 typename DT::elem *__restrict__ hidden,
                                                                 long long BT, int T, int U1, int H,
                                                                 const int *__restrict__ act_lens,
-                                                                const int *__restrict__ label_lens) {
+                                                                const int *__restrict__ label_lens,
+                                                                long long compact_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const long long p = (long long)blockIdx.x * kJW + wave;  // = b*T + t
@@ -154,6 +170,12 @@ __global__ __launch_bounds__(kJW *kWave) void joint_hidden_fwd(const typename DT
     }
     const typename DT::elem *drow = dec_proj + (size_t)b * U1 * H;
     typename DT::elem *hrow = hidden + (size_t)p * U1 * H;
+    if (compact_rows) {  // (kernel-uniform; lengths given) one row per node: frame t of utterance b starts at node
+        // first_b + t (U_b + 1); a frame the buffer has no room for is skipped
+        const long long k0 = nodes_before(act_lens, label_lens, b, T, U1, lane) + (p - (long long)b * T) * nu;
+        if (k0 + nu > compact_rows) return;  // wave-uniform
+        hrow = hidden + (size_t)k0 * H;
+    }
 #pragma unroll 4
     for (int u = 0; u < nu; ++u) {
 #pragma unroll
@@ -179,7 +201,8 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
                                                                 float *__restrict__ partial, long long items, int T,
                                                                 int U1, int H, int nchunk, int nslice,
                                                                 const int *__restrict__ act_lens,
-                                                                const int *__restrict__ label_lens) {
+                                                                const int *__restrict__ label_lens,
+                                                                long long compact_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const long long w = (long long)blockIdx.x * kBW + threadIdx.x / kWave;
     if (w >= items) return;
@@ -208,10 +231,19 @@ __global__ __launch_bounds__(kBW *kWave) void joint_hidden_bwd(const typename DT
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc_e[i][j] = 0.f;
 
-    const size_t frame_stride = (size_t)U1 * H;
+    size_t frame_stride = (size_t)U1 * H;
     const typename DT::elem *hp = hidden + ((size_t)b * T + t0) * frame_stride + colc;
     const typename DT::elem *gp = grad_hidden + ((size_t)b * T + t0) * frame_stride + colc;
     float *pp = partial + ((size_t)b * nchunk + chunk) * frame_stride + col;
+    if (compact_rows && nu > 0) {  // (lengths given) hidden and its gradient hold one row per node: frames of U_b + 1 rows
+        const long long first = nodes_before(act_lens, label_lens, b, T, U1, lane);
+        const long long fit_frames = compact_rows > first ? (compact_rows - first) / nu : 0;  // frames the buffer has room for
+        ntv = (int)min((long long)ntv, max(fit_frames - t0, 0ll));
+        if (ntv == 0) nu = 0;
+        frame_stride = (size_t)nu * H;
+        hp = hidden + ((size_t)first + (size_t)t0 * nu) * H + colc;
+        gp = grad_hidden + ((size_t)first + (size_t)t0 * nu) * H + colc;
+    }
 
     if (ntv == kTC) {  // every chunk but the last: unconditional loads, fully unrolled
         for (int u = 0; u < nu; ++u) {
@@ -405,7 +437,8 @@ inline bool shape_ok(int B, int T, int U1, int H) {
 
 template <typename DT>
 rnntStatus_t launch_fwd(const void *enc_proj, const void *dec_proj, void *hidden, int B, int T, int U1, int H,
-                        hipStream_t st, const int *act_lens = nullptr, const int *label_lens = nullptr) {
+                        hipStream_t st, const int *act_lens = nullptr, const int *label_lens = nullptr,
+                        long long compact_rows = 0) {
     typedef typename DT::elem E;
     const bool vec = H % DT::EPC == 0 && aligned16(enc_proj) && aligned16(dec_proj) && aligned16(hidden);
     const long long BT = (long long)B * T;
@@ -415,12 +448,12 @@ rnntStatus_t launch_fwd(const void *enc_proj, const void *dec_proj, void *hidden
         const int cw = kWave * DT::EPC * kJCH;
         hipLaunchKernelGGL((joint_hidden_fwd<DT, DT::EPC>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0,
                            st, static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
-                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens);
+                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens, compact_rows);
     } else {
         const int cw = kWave * kJCH;
         hipLaunchKernelGGL((joint_hidden_fwd<DT, 1>), dim3((unsigned)gx, (H + cw - 1) / cw), dim3(kJW * kWave), 0, st,
                            static_cast<const E *>(enc_proj), static_cast<const E *>(dec_proj),
-                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens);
+                           static_cast<E *>(hidden), BT, T, U1, H, act_lens, label_lens, compact_rows);
     }
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
@@ -430,7 +463,7 @@ inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintp
 template <typename DT>
 rnntStatus_t launch_bwd(const void *hidden, const void *grad_hidden, void *grad_enc_proj, void *grad_dec_proj,
                         int B, int T, int U1, int H, void *workspace, hipStream_t st, const int *act_lens = nullptr,
-                        const int *label_lens = nullptr) {
+                        const int *label_lens = nullptr, long long compact_rows = 0) {
     typedef typename DT::elem E;
     const size_t piece = 4 * sizeof(E);
     const bool vec = H % 4 == 0 && aligned_to(hidden, piece) && aligned_to(grad_hidden, piece) &&
@@ -445,11 +478,13 @@ rnntStatus_t launch_bwd(const void *hidden, const void *grad_hidden, void *grad_
     if (vec) {
         hipLaunchKernelGGL((joint_hidden_bwd<DT, 4>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
                            static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
-                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens);
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens,
+                           compact_rows);
     } else {
         hipLaunchKernelGGL((joint_hidden_bwd<DT, 1>), dim3((unsigned)gx), dim3(kBW * kWave), 0, st,
                            static_cast<const E *>(hidden), static_cast<const E *>(grad_hidden),
-                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens);
+                           static_cast<E *>(grad_enc_proj), partial, items, T, U1, H, nchunk, nslice, act_lens, label_lens,
+                           compact_rows);
     }
     if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
     const size_t total = (size_t)B * U1 * H;
@@ -533,6 +568,47 @@ rnntStatus_t rnnt_joint_hidden_backward_ragged(const void *hidden, const void *g
         case RNNT_DTYPE_F16:
             return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
                                    label_lens);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t rnnt_joint_hidden_forward_compact(const void *enc_proj, const void *dec_proj, void *hidden,
+                                               long long hidden_rows, const int *act_lens, const int *label_lens, int B,
+                                               int T, int U1, int H, rnntDtype_t dtype, void *stream) {
+    if (enc_proj == nullptr || dec_proj == nullptr || hidden == nullptr || act_lens == nullptr || label_lens == nullptr ||
+        hidden_rows <= 0 || !shape_ok(B, T, U1, H))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32:
+            return launch_fwd<F32>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens, hidden_rows);
+        case RNNT_DTYPE_BF16:
+            return launch_fwd<BF16>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens, hidden_rows);
+        case RNNT_DTYPE_F16:
+            return launch_fwd<F16>(enc_proj, dec_proj, hidden, B, T, U1, H, st, act_lens, label_lens, hidden_rows);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t rnnt_joint_hidden_backward_compact(const void *hidden, const void *grad_hidden, long long hidden_rows,
+                                                void *grad_enc_proj, void *grad_dec_proj, const int *act_lens,
+                                                const int *label_lens, int B, int T, int U1, int H, rnntDtype_t dtype,
+                                                void *workspace, void *stream) {
+    if (hidden == nullptr || grad_hidden == nullptr || grad_enc_proj == nullptr || grad_dec_proj == nullptr ||
+        act_lens == nullptr || label_lens == nullptr || workspace == nullptr || hidden_rows <= 0 ||
+        !shape_ok(B, T, U1, H) || !aligned16(workspace))
+        return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case RNNT_DTYPE_F32:
+            return launch_bwd<F32>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                   label_lens, hidden_rows);
+        case RNNT_DTYPE_BF16:
+            return launch_bwd<BF16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                    label_lens, hidden_rows);
+        case RNNT_DTYPE_F16:
+            return launch_bwd<F16>(hidden, grad_hidden, grad_enc_proj, grad_dec_proj, B, T, U1, H, workspace, st, act_lens,
+                                   label_lens, hidden_rows);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }

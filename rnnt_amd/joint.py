@@ -84,6 +84,44 @@ class _JointHidden(torch.autograd.Function):
         return grad_enc, grad_dec, None, None
 
 
+class _JointHiddenCompact(torch.autograd.Function):
+    """``joint_hidden`` with the result in the compacted node order: ``[nodes, H]``, one row per lattice node."""
+
+    @staticmethod
+    def forward(ctx, enc_proj, dec_proj, act_lens, label_lens, nodes):
+        B, T, H = enc_proj.shape
+        U1 = dec_proj.shape[1]
+        dev = enc_proj.device
+        enc_proj = enc_proj.contiguous()
+        dec_proj = dec_proj.contiguous()
+        with torch.cuda.device(dev):
+            hidden = torch.empty((int(nodes), H), dtype=enc_proj.dtype, device=dev)
+            _lib.check(_lib.load().rnnt_joint_hidden_forward_compact(
+                enc_proj.data_ptr(), dec_proj.data_ptr(), hidden.data_ptr(), int(nodes), act_lens.data_ptr(),
+                label_lens.data_ptr(), B, T, U1, H, _DTYPES[enc_proj.dtype], torch.cuda.current_stream(dev).cuda_stream),
+                "rnnt_joint_hidden_forward_compact")
+        ctx.save_for_backward(hidden, act_lens, label_lens)
+        ctx.shape = (B, T, U1, H)
+        return hidden
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_hidden):
+        hidden, act_lens, label_lens = ctx.saved_tensors
+        B, T, U1, H = ctx.shape
+        dev = hidden.device
+        grad_hidden = grad_hidden.to(hidden.dtype).contiguous()
+        with torch.cuda.device(dev):
+            grad_enc = torch.empty((B, T, H), dtype=hidden.dtype, device=dev)
+            grad_dec = torch.empty((B, U1, H), dtype=hidden.dtype, device=dev)
+            ws = torch.empty(_workspace_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.load().rnnt_joint_hidden_backward_compact(
+                hidden.data_ptr(), grad_hidden.data_ptr(), hidden.shape[0], grad_enc.data_ptr(), grad_dec.data_ptr(),
+                act_lens.data_ptr(), label_lens.data_ptr(), B, T, U1, H, _DTYPES[hidden.dtype], ws.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream), "rnnt_joint_hidden_backward_compact")
+        return grad_enc, grad_dec, None, None, None
+
+
 class _Projection(torch.autograd.Function):
     """``F.linear(x, weight, bias)`` over the rows of ``x`` ``[n, H]`` (fp32), with the weight gradient formed as a
     split-K product.  ``grad_weight = g^T x`` contracts over n = 10^5 .. 10^6 rows into a ``[V, H]`` result of a few
@@ -131,13 +169,16 @@ def _project(x, linear):
     return linear(x)
 
 
-def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, label_lens=None) -> torch.Tensor:
+def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, label_lens=None, nodes=None) -> torch.Tensor:
     """``tanh(enc_proj[:, :, None, :] + dec_proj[:, None, :, :])`` → ``[B, T, U+1, H]`` on the MI355X.
 
     ``enc_proj`` ``[B, T, H]``, ``dec_proj`` ``[B, U+1, H]``, same dtype (fp32, bf16 or fp16) and device.
     With ``act_lens`` / ``label_lens`` (int32 ``[B]`` on the device): the ragged form for a consumer that ignores the
     rows outside the utterances' lattices — only rows ``t < act_lens[b]``, ``u <= label_lens[b]`` are written (the
     others are UNINITIALISED), and backward reads ``hidden`` and its gradient only there.
+    With ``nodes`` as well (the number of lattice nodes, ``rnnt_amd.count_lattice_nodes``): the result is ``[nodes, H]``
+    in the COMPACTED node order — row ``k`` is node ``k`` of ``rnnt_amd.compact_rowmap``, where a projection over the
+    nodes and ``rnnt_amd.rnnt_loss_compact`` read it; no ``[B, T, U+1, H]`` tensor exists in either direction.
     """
     if enc_proj.dim() != 3 or dec_proj.dim() != 3:
         raise ValueError("enc_proj must be [B,T,H] and dec_proj [B,U+1,H]")
@@ -157,12 +198,15 @@ def joint_hidden(enc_proj: torch.Tensor, dec_proj: torch.Tensor, act_lens=None, 
             if t.dtype is not torch.int32 or t.device != enc_proj.device or t.shape != (enc_proj.shape[0],) \
                     or not t.is_contiguous():
                 raise ValueError(f"{name} must be a contiguous int32 [B] tensor on enc_proj's device")
+    if nodes is not None:
+        if act_lens is None or int(nodes) < 1:
+            raise ValueError("nodes= needs the two length tensors and at least one node")
+        return _JointHiddenCompact.apply(enc_proj, dec_proj, act_lens, label_lens, int(nodes))
     return _JointHidden.apply(enc_proj, dec_proj, act_lens, label_lens)
 
 
 # JointNet.transducer_loss, lengths known on the host: a batch with fewer lattice nodes than this share of the rows of
-# its [B, T, U+1] tensor takes the compacted route (gather + GEMM over the nodes + rnnt_loss_compact); a fuller one is
-# not worth the gather.
+# its [B, T, U+1] tensor takes the compacted route (hidden layer, projection GEMMs and the loss on one row per node).
 COMPACT_BELOW = 0.9
 
 
@@ -178,11 +222,12 @@ class JointNet(nn.Module):
             nn.Linear(inner_dim, vocab_size, bias=True),
         )
 
-    def hidden(self, enc_state, dec_state, act_lens=None, label_lens=None):
+    def hidden(self, enc_state, dec_state, act_lens=None, label_lens=None, nodes=None):
         """``[B, T, U+1, inner_dim]``: what the reference's ``mlp[:2]`` (Linear + Tanh) returns on the repeated and
         concatenated (or summed) states (model.py:46-58), from ``enc_state`` ``[B, T, He]`` and ``dec_state``
         ``[B, U+1, Hd]`` without building the ``[B, T, U+1, He+Hd]`` tensor.  With the two length tensors: the ragged
-        form of :func:`joint_hidden` (rows outside the lattices uninitialised)."""
+        form of :func:`joint_hidden` (rows outside the lattices uninitialised); with ``nodes`` too: ``[nodes, inner_dim]``
+        in the compacted node order."""
         first = self.mlp[0]
         if self.joint == "concat":
             he = enc_state.size(-1)
@@ -193,7 +238,7 @@ class JointNet(nn.Module):
             w_enc = w_dec = first.weight
         enc_proj = F.linear(enc_state, w_enc, first.bias)      # [B, T, H]
         dec_proj = F.linear(dec_state, w_dec)                  # [B, U+1, H]
-        return joint_hidden(enc_proj, dec_proj, act_lens, label_lens)
+        return joint_hidden(enc_proj, dec_proj, act_lens, label_lens, nodes)
 
     def transducer_loss(self, enc_state, dec_state, labels, act_lens, label_lens, blank=0, reduction="mean"):
         """The reference's two lines ``logits = self.joint(enc_state, dec_state)`` and
@@ -260,11 +305,9 @@ class JointNet(nn.Module):
             # fp32 states (the reference's own precision) and the shapes the fused kernels leave to the library: the
             # projection and the loss's three passes run over the lattice nodes only (rnnt_amd/compact.py) — the two
             # fp32 GEMMs of the projection's forward and backward are most of this step, and they shrink with the nodes
-            from .compact import compact_rowmap, rnnt_loss_compact
+            from .compact import rnnt_loss_compact
 
-            rowmap = compact_rowmap(act_lens, label_lens, T, U1, valid_nodes)
-            hidden = self.hidden(enc_state, dec_state, act_lens, label_lens)       # rows outside the lattices: untouched
-            nodes = hidden.view(B * T * U1, -1).index_select(0, rowmap.long())     # [n, H]
+            nodes = self.hidden(enc_state, dec_state, act_lens, label_lens, valid_nodes)   # [n, H]: one row per node
             return rnnt_loss_compact(_project(nodes, out), labels, act_lens, label_lens, T, blank=blank,
                                      reduction=reduction, exact_rows=True)
         hidden = self.hidden(enc_state, dec_state)

@@ -349,6 +349,72 @@ def test_ragged_hidden_layer(dtype):
         rnnt_amd.joint_hidden(enc, dec, al.to(DEV).long(), ll.to(DEV).long())
 
 
+@pytest.mark.parametrize("dtype,H", [(torch.float32, 512), (torch.bfloat16, 512), (torch.float16, 330), (torch.float32, 37)])
+def test_hidden_layer_in_the_compacted_node_order(dtype, H):
+    """rnnt_joint_hidden_forward_compact / _backward_compact: row k of the [n, H] result is node k of
+    rnnt_compact_rows, with the bits of the dense layer's row; backward gives the dense pair's gradients for a gradient
+    that is zero outside the lattices; a buffer with slack keeps its surplus rows, one that is too small drops whole
+    frames."""
+    import rnnt_amd
+
+    B, T, U1 = 6, 45, 9
+    g = torch.Generator().manual_seed(5)
+    enc = torch.randn(B, T, H, generator=g).to(dtype).to(DEV)
+    dec = torch.randn(B, U1, H, generator=g).to(dtype).to(DEV)
+    al = np.array([45, 5, 16, 17, 50, 33], dtype=np.int32)            # utterance 4 does not fit: no nodes
+    ll = np.array([8, 0, 3, 8, 2, 5], dtype=np.int32)
+    ald, lld = torch.from_numpy(al).to(DEV), torch.from_numpy(ll).to(DEV)
+    rows = torch.from_numpy(host_rowmap(al, ll, T, U1)).to(DEV)
+    n = rows.numel()
+    assert n == rnnt_amd.count_lattice_nodes(al, ll, T, U1)
+    e1, d1 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    dense = rnnt_amd.joint_hidden(e1, d1)
+    e2, d2 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    nodes = rnnt_amd.joint_hidden(e2, d2, ald, lld, nodes=n)
+    assert nodes.shape == (n, H)
+    assert torch.equal(nodes, dense.view(-1, H)[rows])
+    go = torch.randn(n, H, generator=g).to(dtype).to(DEV)
+    full = torch.zeros(B * T * U1, H, dtype=dtype, device=DEV)
+    full[rows] = go
+    dense.backward(full.view(B, T, U1, H))
+    nodes.backward(go)
+    assert torch.equal(e2.grad, e1.grad) and torch.equal(d2.grad, d1.grad)
+    assert float(e2.grad[4].float().abs().sum()) == 0.0 and float(d2.grad[4].float().abs().sum()) == 0.0
+
+    # slack: rows past the last node are not written; too small: the frames that do not fit are dropped whole
+    lib = rnnt_amd._lib.load()
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.full((n + 7, H), 3.0, dtype=dtype, device=DEV)
+    assert lib.rnnt_joint_hidden_forward_compact(enc.data_ptr(), dec.data_ptr(), buf.data_ptr(), n + 7, ald.data_ptr(),
+                                                 lld.data_ptr(), B, T, U1, H, dt, stream) == 0
+    assert torch.equal(buf[:n], nodes) and bool((buf[n:] == 3.0).all())
+    cut = n - 4                                                       # the last utterance has 6 rows per frame
+    buf = torch.full((cut, H), 3.0, dtype=dtype, device=DEV)
+    assert lib.rnnt_joint_hidden_forward_compact(enc.data_ptr(), dec.data_ptr(), buf.data_ptr(), cut, ald.data_ptr(),
+                                                 lld.data_ptr(), B, T, U1, H, dt, stream) == 0
+    assert torch.equal(buf[:n - 6], nodes[:n - 6]) and bool((buf[n - 6:] == 3.0).all())
+    ge, gd = torch.empty_like(enc), torch.empty_like(dec)
+    nbytes = ctypes.c_size_t(0)
+    assert lib.rnnt_joint_hidden_workspace_size(B, T, U1, H, ctypes.byref(nbytes)) == 0
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+    hid_cut, go_cut = nodes.detach()[:cut].contiguous(), go[:cut].contiguous()
+    assert lib.rnnt_joint_hidden_backward_compact(hid_cut.data_ptr(), go_cut.data_ptr(), cut, ge.data_ptr(), gd.data_ptr(),
+                                                  ald.data_ptr(), lld.data_ptr(), B, T, U1, H, dt, ws.data_ptr(), stream) == 0
+    e3, d3 = enc.clone().requires_grad_(True), dec.clone().requires_grad_(True)
+    full = torch.zeros(B * T * U1, H, dtype=dtype, device=DEV)
+    full[rows[:n - 6]] = go[:n - 6]                                    # the last frame of the last utterance: dropped
+    rnnt_amd.joint_hidden(e3, d3).backward(full.view(B, T, U1, H))
+    assert torch.equal(ge, e3.grad) and torch.equal(gd, d3.grad)
+    # argument checks
+    assert lib.rnnt_joint_hidden_forward_compact(enc.data_ptr(), dec.data_ptr(), buf.data_ptr(), 0, ald.data_ptr(),
+                                                 lld.data_ptr(), B, T, U1, H, dt, stream) != 0
+    assert lib.rnnt_joint_hidden_forward_compact(enc.data_ptr(), dec.data_ptr(), buf.data_ptr(), cut, None,
+                                                 lld.data_ptr(), B, T, U1, H, dt, stream) != 0
+    with pytest.raises(ValueError):
+        rnnt_amd.joint_hidden(enc, dec, nodes=n)
+
+
 def _random_compact_case(rng, it):
     B = int(rng.integers(1, 9))
     T = int(rng.integers(1, 160))
