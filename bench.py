@@ -93,24 +93,32 @@ def cpu_baseline(w, acts_dev, labels_dev, al, ll, sample_B, reps):
     labels = labels_dev[:B].cpu().numpy()
     al, ll = np.ascontiguousarray(al[:B]), np.ascontiguousarray(ll[:B])
     threads = oracle.max_threads()
-    oracle.rnnt_loss_c(acts[:1], labels[:1], al[:1], ll[:1])  # warm-up (page in, thread pool)
+    if B > 1:  # warm-up (page in, thread pool); a one-utterance sample (config 5) is its own warm-up
+        oracle.rnnt_loss_c(acts[:1], labels[:1], al[:1], ll[:1])
     ts = []
-    for _ in range(reps):
+    for i in range(reps):  # bounded: stop early once ~20 s of CPU work are on the clock (large lattices: config 5)
         t0 = time.perf_counter()
         c, gr, _ = oracle.rnnt_loss_c(acts, labels, al, ll, want_grads=True)
         oracle.reduce_like_upstream(c, None, "mean")
         ts.append(time.perf_counter() - t0)
         del gr
+        print(f"[bench] cpu baseline run {i + 1}: {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+        if sum(ts) > 20.0:
+            break
+    reps = len(ts)
     t = float(np.median(ts))
     # the upstream-shaped path holds the logits, the log-probs and two gradients at once: half the sample
     Bu = max(1, min(B, int(1.25e9 // per_utt)))
     tu = []
-    for _ in range(max(2, reps // 2)):
+    for i in range(max(2, reps // 2)):
         t0 = time.perf_counter()
         lu, gu = oracle.rnnt_loss_upstream_shaped(acts[:Bu], labels[:Bu], al[:Bu], ll[:Bu], reduction="mean",
                                                   grad_output=0.5)
         tu.append(time.perf_counter() - t0)
         del gu
+        print(f"[bench] cpu baseline (upstream-shaped) run {i + 1}: {tu[-1]:.2f} s", file=sys.stderr, flush=True)
+        if sum(tu) > 10.0:
+            break
     tu = float(np.median(tu))
     lens = "uniform lengths" if not w["ragged"] else "the batch's own ragged lengths"
     return {
