@@ -9,7 +9,8 @@ projects only them (a library GEMM over ``n`` rows instead of ``B*T*(U+1)``) and
 passes with one row per node.  Same costs as ``rnnt_loss`` on the padded tensor, bit for bit; the gradient holds the
 node rows of ``rnnt_loss``'s, bit for bit (rows of whole 128-byte lines, longer than 2 KiB; otherwise to the last bit of each row's
 log-sum), and no zeros for padding are written.  ``rnnt_amd.JointNet.transducer_loss``
-takes this route for fp32 states (the reference's own precision) when the lengths arrive on the host.
+takes this route for fp32 states (the reference's own precision) when the lengths arrive on the host; its own hidden
+layer is written in the compacted order directly (``rnnt_amd.joint_hidden(..., nodes=n)``), so it needs no map.
 No CPU path, no fallback.
 """
 from __future__ import annotations
