@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--ragged", type=int, default=None, metavar="SEED",
+                    help="lengths as BASELINE config 3 scaled to the shape; the kernels then skip the rows outside the lattices")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float32 if args.dtype == "f32" else torch.bfloat16
@@ -49,9 +51,17 @@ def main():
     ep = torch.nn.functional.linear(enc, lin.weight[:, :He], lin.bias).detach().requires_grad_(True)
     dp = torch.nn.functional.linear(dec, lin.weight[:, He:]).detach().requires_grad_(True)
     state = {}
+    lens = ()
+    if args.ragged is not None:
+        hg = torch.Generator().manual_seed(args.ragged)
+        al = torch.randint(max(1, T // 8), T + 1, (B,), generator=hg, dtype=torch.int32)
+        ll = torch.randint((U1 - 1) // 6, U1, (B,), generator=hg, dtype=torch.int32)
+        al[0], ll[0] = T, U1 - 1
+        n = rnnt_amd.count_lattice_nodes(al, ll) * H
+        lens = (al.to(dev), ll.to(dev))
 
     def k_fwd():
-        state["h"] = rnnt_amd.joint_hidden(ep, dp)
+        state["h"] = rnnt_amd.joint_hidden(ep, dp, *lens)
 
     def k_bwd():
         ep.grad = dp.grad = None
@@ -62,7 +72,7 @@ def main():
         lin.zero_grad(set_to_none=True)
         e = torch.nn.functional.linear(enc, lin.weight[:, :He], lin.bias)
         d = torch.nn.functional.linear(dec, lin.weight[:, He:])
-        rnnt_amd.joint_hidden(e, d).backward(gh)
+        rnnt_amd.joint_hidden(e, d, *lens).backward(gh)
 
     def ref_all():
         enc.grad = dec.grad = None
@@ -76,7 +86,8 @@ def main():
     t_ours = timed(ours_all, args.steps, args.warmup)
     t_ref = timed(ref_all, args.steps, args.warmup)
     out = {
-        "workload": f"joint hidden layer B{B} T{T} U{U1 - 1} He{He} Hd{Hd} H{H} {args.dtype}",
+        "workload": f"joint hidden layer B{B} T{T} U{U1 - 1} He{He} Hd{Hd} H{H} {args.dtype}"
+                    + ("" if args.ragged is None else f", ragged (seed {args.ragged}): {n // H} of {B * T * U1} rows are nodes"),
         "joint_hidden_fwd_ms": round(t_fwd, 4),
         "fwd_GBs": round(n * esz / t_fwd / 1e6, 1),
         "joint_hidden_bwd_ms": round(t_bwd, 4),
