@@ -7,7 +7,7 @@ One "step" = RNNTLoss forward + backward over one synthetic batch already reside
 N=1 runs BASELINE.json configs[1] (B=32, T=400, U=40, V=4232, fp32).  For N>1 the driver starts
 one rank per GPU with torch.distributed.run; every rank owns B=32 utterances (weak scaling, so
 N=8 is configs[3], B=256) and the ranks exchange only the per-utterance costs (one RCCL
-all-reduce of 4·B bytes, rnnt_amd/parallel.py).
+all-gather of 4·B bytes, rnnt_amd/parallel.py).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (K3, the fused gradient
 pass): algorithmic bytes per launch (read N_valid + write N_full elements) over its mean
@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--cpu-sample-b", type=int, default=32)
     ap.add_argument("--cpu-reps", type=int, default=6)
     ap.add_argument("--force-sharded", action="store_true",
-                    help="use the sharded harness (RCCL all-reduce of costs) even with one rank")
+                    help="use the sharded harness (RCCL all-gather of costs) even with one rank")
     ap.add_argument("--no-check-lengths", action="store_true",
                     help="skip the host-side length check (fully asynchronous forward)")
     args = ap.parse_args()
@@ -302,7 +302,7 @@ def main():
                         f"{'ragged' if w['ragged'] else 'uniform'} lengths, N(0,1) logits, grad_output=0.5, "
                         f"reduction=mean",
             "global_batch": B * world,
-            "parallelism": f"batch-sharded x{world}, all-reduce of per-utterance costs" if sharded else "single GPU",
+            "parallelism": f"batch-sharded x{world}, all-gather of per-utterance costs" if sharded else "single GPU",
             "check_lengths": not args.no_check_lengths,
         },
         "roofline": {

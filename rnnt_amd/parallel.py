@@ -8,9 +8,10 @@ The vendored ``src/parallel/parallel.py`` of the reference is dead code
 
 Utterances are independent, so each rank keeps its own slice of the logits and
 of the gradient; nothing of size N ever crosses xGMI.  The only exchange is the
-per-utterance cost vector (4·B bytes): every rank writes its costs into its
-slice of a zeroed ``[B_global]`` vector and one ``all_reduce(SUM)`` (RCCL on
-GPUs, gloo in the CPU tests) completes it.  Adding zeros is exact, so the
+per-utterance cost vector (4·B bytes): equal contiguous shards are laid end to
+end by one ``all_gather``; any other partition writes its costs into its slots
+of a zeroed ``[B_global]`` vector and one ``all_reduce(SUM)`` completes it (RCCL
+on GPUs, gloo in the CPU tests).  Both are exact (adding zeros is), so the
 result is bit-identical on every rank and to the unsharded cost vector; the
 scalar is then formed in a fixed summation order.  Backward needs no
 collective: each rank scales its local gradient by ``grad_out / B_global``
@@ -140,6 +141,20 @@ def ordered_reduce(costs: torch.Tensor, reduction: str) -> torch.Tensor:
     return s.reshape(1)
 
 
+class _GlobalLoss(torch.autograd.Function):
+    """Value: the global loss formed from the gathered cost vector in a fixed order.  Gradient: ``factor`` (1 or
+    1 / B_global) times the upstream gradient for each LOCAL utterance — the other ranks' utterances are their own."""
+
+    @staticmethod
+    def forward(ctx, local, gathered, reduction, factor):
+        ctx.n, ctx.factor = local.shape[0], factor
+        return ordered_reduce(gathered, reduction)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (grad.reshape(1).to(torch.float32) * ctx.factor).expand(ctx.n), None, None, None
+
+
 class ShardedRNNTLoss(torch.nn.Module):
     """RNN-T loss over a batch that is sharded across the ranks of a process group.
 
@@ -157,7 +172,7 @@ class ShardedRNNTLoss(torch.nn.Module):
             Off by default here: it costs one host wait per step and rank, and a shard of a ragged batch rarely has
             ``T == max(act_lens)`` anyway (out-of-range lengths still give a NaN cost, never a fault).
 
-    Nothing in ``forward`` waits on the host: the all-reduce of the per-utterance costs is launched asynchronously
+    Nothing in ``forward`` waits on the host: the collective of the per-utterance costs is launched asynchronously
     right behind K2 and waited for (on the stream, for RCCL) only where the scalar is formed.
     """
 
@@ -210,14 +225,19 @@ class ShardedRNNTLoss(torch.nn.Module):
             raise RuntimeError("loss_fn must return one cost per local utterance")
 
         # the one collective: per-utterance costs, 4*B_global bytes, latency-bound
-        gathered = torch.zeros(global_batch, dtype=torch.float32, device=local.device)
-        if where is not None:
-            where = where.to(local.device, non_blocking=True)
-            gathered[where] = local.detach()
+        if where is None and global_batch == b_local * world and offset == rank * b_local:
+            # equal contiguous shards (BASELINE config 4): the cost vector is the ranks' vectors laid end to end
+            gathered = torch.empty(global_batch, dtype=torch.float32, device=local.device)
+            work = dist.all_gather_into_tensor(gathered, local.detach().to(torch.float32).contiguous(),
+                                               group=self.group, async_op=True)
         else:
-            gathered[offset:offset + b_local] = local.detach()
-        work = dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        local_sum = local.sum() if self.reduction != "none" else None   # (independent of the collective)
+            gathered = torch.zeros(global_batch, dtype=torch.float32, device=local.device)
+            if where is not None:
+                where = where.to(local.device, non_blocking=True)
+                gathered[where] = local.detach()
+            else:
+                gathered[offset:offset + b_local] = local.detach()
+            work = dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         work.wait()  # RCCL: the compute stream waits for the collective's stream; the host does not block
 
         if self.reduction == "none":
@@ -228,6 +248,5 @@ class ShardedRNNTLoss(torch.nn.Module):
                 out[offset:offset + b_local] = local
             return out
         factor = 1.0 / global_batch if self.reduction == "mean" else 1.0
-        value = ordered_reduce(gathered, self.reduction)
         # value of the global loss, gradient only through this rank's utterances
-        return value + (local_sum - local_sum.detach()) * factor
+        return _GlobalLoss.apply(local, gathered, self.reduction, factor)
