@@ -77,6 +77,20 @@ def test_invalid_arguments_return_status_not_crash():
     assert lib.rnnt_backward(None, None, None, None, None, 5, 1, None, 0, ctypes.c_float(1.0), None, opts) == 2
     assert lib.compute_rnnt_loss(None, None, None, None, None, 5, 1, None, None, opts) == 2
     assert lib.rnnt_reduce_costs(None, None, 4, 1, None) == 2
+    # the entry points of the compacted node order and of the joint's hidden layer likewise
+    assert lib.rnnt_compact_rows(None, None, 1, 4, 3, 10, None, None, None) == 2
+    assert lib.rnnt_forward_compact(None, 10, None, None, None, 5, 1, None, None, 1, None, opts) == 2
+    assert lib.rnnt_backward_compact(None, None, 10, None, None, None, 5, 1, None, 0, ctypes.c_float(1.0), None, opts) == 2
+    assert lib.rnnt_joint_hidden_forward(None, None, None, 1, 4, 3, 8, 0, None) == 2
+    assert lib.rnnt_joint_hidden_backward(None, None, None, None, 1, 4, 3, 8, 0, None, None) == 2
+    assert lib.rnnt_joint_hidden_forward_ragged(None, None, None, None, None, 1, 4, 3, 8, 0, None) == 2
+    assert lib.rnnt_joint_hidden_backward_ragged(None, None, None, None, None, None, 1, 4, 3, 8, 0, None, None) == 2
+    assert lib.rnnt_joint_hidden_forward_compact(None, None, None, 10, None, None, 1, 4, 3, 8, 0, None) == 2
+    assert lib.rnnt_joint_hidden_backward_compact(None, None, 10, None, None, None, None, 1, 4, 3, 8, 0, None, None) == 2
+    nbytes = ctypes.c_size_t(0)
+    assert lib.rnnt_joint_hidden_workspace_size(0, 4, 3, 8, ctypes.byref(nbytes)) == 2
+    assert lib.rnnt_joint_hidden_workspace_size(2, 33, 3, 8, ctypes.byref(nbytes)) == 0
+    assert nbytes.value == 2 * 3 * 3 * 8 * 4          # B * ceil(T / 16) frame chunks * U1 * H fp32 partial sums
     with pytest.raises(RuntimeError, match="invalid value"):
         _lib.check(2, "x")
 
