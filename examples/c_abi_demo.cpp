@@ -1,5 +1,6 @@
 // c_abi_demo.cpp — calls librnnt_mi355.so through include/rnnt_mi355.h with no PyTorch in sight:
-// hipMalloc'ed buffers, the upstream-shaped compute_rnnt_loss() and the split forward/backward.
+// hipMalloc'ed buffers, the upstream-shaped compute_rnnt_loss(), the split forward/backward and the loss on a ragged
+// batch's lattice nodes only (rnnt_compact_rows / rnnt_forward_compact / rnnt_backward_compact).
 // Input is the B1·T2·U2·V5 known-answer vector; prints costs and gradients
 // so tests/test_gpu_c_abi.py can compare them.  Build: see __graft_entry__.build().
 #include <hip/hip_runtime.h>
@@ -90,7 +91,64 @@ int main() {
     for (float g : grads) std::printf(" %.9g", g);
     std::printf("\n");
 
-    // 3. errors are status codes
+    // 3. a ragged batch in the compacted node order: utterance 0 is the vector above, utterance 1 uses one frame and one
+    //    label of a [2, 2, 3, 5] tensor.  rnnt_compact_rows numbers the 6 + 2 nodes inside the lattices on the device; the
+    //    logits the loss sees hold one row per NODE (a caller that projects only those rows never builds the padding).
+    {
+        const int B2 = 2, nodes = 2 * 3 + 1 * 2;
+        std::vector<float> padded(2 * n, 0.25f);
+        for (size_t i = 0; i < n; ++i) padded[i] = acts[i];
+        for (size_t i = n; i < 2 * n; ++i) padded[i] = 0.05f * (float)((i * 7) % 11);
+        const int labels2[4] = {1, 2, 3, 0}, al2[2] = {2, 1}, ll2[2] = {2, 1};
+        float *d_nodes, *d_ngrads, *d_costs2, *d_loss2, *d_go2;
+        int *d_labels2, *d_al2, *d_ll2, *d_rowmap;
+        void *d_ws2, *d_scratch;
+        size_t ws2 = 0;
+        RNNT_OK(get_workspace_size(T, U1, B2, 1, &ws2));
+        HIP_OK(hipMalloc(&d_nodes, nodes * V * sizeof(float)));
+        HIP_OK(hipMalloc(&d_ngrads, nodes * V * sizeof(float)));
+        HIP_OK(hipMalloc(&d_costs2, B2 * sizeof(float)));
+        HIP_OK(hipMalloc(&d_loss2, B2 * sizeof(float)));
+        HIP_OK(hipMalloc(&d_go2, B2 * sizeof(float)));
+        HIP_OK(hipMalloc(&d_labels2, sizeof(labels2)));
+        HIP_OK(hipMalloc(&d_al2, sizeof(al2)));
+        HIP_OK(hipMalloc(&d_ll2, sizeof(ll2)));
+        HIP_OK(hipMalloc(&d_rowmap, nodes * sizeof(int)));
+        HIP_OK(hipMalloc(&d_ws2, ws2));
+        HIP_OK(hipMalloc(&d_scratch, 16 * (B2 + 1)));
+        HIP_OK(hipMemcpy(d_labels2, labels2, sizeof(labels2), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_al2, al2, sizeof(al2), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_ll2, ll2, sizeof(ll2), hipMemcpyHostToDevice));
+        RNNT_OK(rnnt_compact_rows(d_al2, d_ll2, B2, T, U1, nodes, d_rowmap, d_scratch, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<int> rowmap(nodes);
+        HIP_OK(hipMemcpy(rowmap.data(), d_rowmap, nodes * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<float> rows((size_t)nodes * V);
+        std::printf("compact_rowmap");
+        for (int k = 0; k < nodes; ++k) {
+            std::printf(" %d", rowmap[k]);
+            for (int v = 0; v < V; ++v) rows[(size_t)k * V + v] = padded[(size_t)rowmap[k] * V + v];
+        }
+        std::printf("\n");
+        HIP_OK(hipMemcpy(d_nodes, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+        const float ones[2] = {1.0f, 1.0f};
+        HIP_OK(hipMemcpy(d_go2, ones, sizeof(ones), hipMemcpyHostToDevice));
+        rnntOptions opt2 = opt;
+        RNNT_OK(rnnt_forward_compact(d_nodes, nodes, d_labels2, d_al2, d_ll2, V, B2, d_costs2, d_loss2, RNNT_REDUCTION_NONE,
+                                     d_ws2, opt2));
+        RNNT_OK(rnnt_backward_compact(d_nodes, d_ngrads, nodes, d_labels2, d_al2, d_ll2, V, B2, d_go2, 1, 1.0f, d_ws2, opt2));
+        HIP_OK(hipStreamSynchronize(stream));
+        float costs2[2];
+        std::vector<float> ngrads((size_t)nodes * V);
+        HIP_OK(hipMemcpy(costs2, d_costs2, sizeof(costs2), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ngrads.data(), d_ngrads, ngrads.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::printf("compact_costs %.9g %.9g\n", costs2[0], costs2[1]);
+        std::printf("compact_grads");
+        for (float g : ngrads) std::printf(" %.9g", g);
+        std::printf("\n");
+    }
+
+    // 4. errors are status codes
     rnntOptions bad = opt;
     bad.blank_label = V;  // out of range
     std::printf("bad_blank_status %d (%s)\n",

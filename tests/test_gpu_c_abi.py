@@ -1,6 +1,6 @@
 """GPU: the C ABI used from a plain C++ host program (examples/c_abi_demo.cpp, no PyTorch, no Python
-in the compute path): hipMalloc'ed buffers, compute_rnnt_loss and the forward/backward split, on the
-upstream known-answer vector."""
+in the compute path): hipMalloc'ed buffers, compute_rnnt_loss, the forward/backward split and the compacted node
+order, on the upstream known-answer vector."""
 import os
 import subprocess
 
@@ -28,3 +28,11 @@ def test_c_host_program_reproduces_kat1():
     grads_half = np.array([float(v) for v in lines["grads_half"]]).reshape(KAT1["grads"].shape)
     assert np.abs(grads_half - 0.5 * KAT1["grads"]).max() <= 1e-6
     assert lines["bad_blank_status"][0] == "2"
+    # the ragged batch in the compacted node order: utterance 0 is KAT-1, found again through one row per node
+    assert [int(v) for v in lines["compact_rowmap"]] == [0, 1, 2, 3, 4, 5, 6, 7]
+    ccosts = [float(v) for v in lines["compact_costs"]]
+    assert abs(ccosts[0] - KAT1["cost"]) <= 1e-5 * KAT1["cost"] and np.isfinite(ccosts[1]) and ccosts[1] > 0
+    cgrads = np.array([float(v) for v in lines["compact_grads"]])
+    assert cgrads.size == 8 * 5
+    assert np.abs(cgrads[:30].reshape(KAT1["grads"].shape) - KAT1["grads"]).max() <= 1e-6
+    assert np.abs(cgrads[30:].reshape(2, 5).sum(axis=1)).max() <= 1e-6       # every node's gradient row sums to zero
