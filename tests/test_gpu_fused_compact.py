@@ -171,6 +171,37 @@ def test_compact_forward_and_backward(B, T, U, V, dtype, what, exact_cap):
     assert bool(torch.isnan(dh3.view(-1, H)[~inside].float()).all())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_compact_on_peaked_logits(dtype):
+    """SURVEY §8d's "peaked" distribution through the fused kernels: logits of a wide dynamic range (weights four times
+    the other tests', sigma of a logit about 6, extremes beyond +-30) and a blank logit 8 above the rest — what a trained
+    model emits.  Costs against the C oracle on the stored logits, gradients against K3 on the same logits."""
+    B, T, U, V, H = 4, 70, 12, 1304, 512
+    hidden, weight, bias, labels, al, ll = make_inputs(B, T, U, V, H, dtype, seed=77)
+    weight = (weight.float() * 4.0).to(dtype)
+    bias = bias.float()
+    bias[0] += 8.0
+    bias = bias.to(dtype)
+    U1, ld = U + 1, (V + 127) // 128 * 128
+    rows = host_rowmap(al, ll, T, U1)
+    n = len(rows)
+    st, logits, costs, ws, cws = forward_compact(poison_padding(hidden, al, ll), weight, bias, labels, al, ll, ld, n)
+    assert st == 0
+    stored = logits[:n, :V].float()
+    assert float(stored.max()) > 25.0 and float(stored.min()) < -25.0 and float(stored.std()) > 4.0
+    full = torch.zeros(B * T * U1, V, dtype=dtype, device=DEV)
+    full[torch.from_numpy(rows).to(DEV)] = logits[:n, :V]
+    full = full.view(B, T, U1, V)
+    c, _, _ = oracle.rnnt_loss_c(full.float().cpu().numpy(), labels, al, ll, want_grads=False)
+    np.testing.assert_allclose(costs.cpu().numpy(), c, rtol=1e-5, atol=0)
+    go = np.linspace(0.25, 1.5, B).astype(np.float32)
+    g = k3_c_abi(full.contiguous(), labels, al, ll, ws, go, 1, 1.0)
+    st, dh, dw, db = backward_compact(poison_padding(hidden, al, ll), weight, logits, ld, n, labels, al, ll, ws, cws,
+                                      go, 1, 1.0)
+    assert st == 0
+    check_against_k3(hidden, weight, g, dh, dw, db)
+
+
 def test_compact_on_a_batch_without_padding_equals_the_dense_calls():
     """Uniform lengths: the compacted order is the tensor's order; logits, costs and all three gradients are the dense
     entry points' bit for bit (same tiles, same node ranges, same order of every sum)."""
